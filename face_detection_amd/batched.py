@@ -1,0 +1,114 @@
+"""Batched entry points of the SSD box pipeline (one set of launches per batch).
+
+match_encode_batch replaces a Python loop of compute_target (reference
+utils/box_utils.py:47-98, called per image at utils/datasets.py:152); decode_nms_batch
+replaces the per-image post-processing block of reference inference.py:33-83.  Results
+equal that loop image by image.
+"""
+import numpy as np
+
+from . import _lib
+from .runtime import AnchorGrid, _ptr, default_context, from_device, require_gpu, to_device
+
+
+def _anchor_source(anchors, device):
+    """(geometry handle or None, anchor tensor or None, A, keepalive)"""
+    if isinstance(anchors, AnchorGrid):
+        if anchors.device != device:
+            raise ValueError("anchors were generated for cuda:%d, the current device is cuda:%d"
+                             % (anchors.device, device))
+        return anchors.geometry.handle, None, anchors.shape[0], anchors
+    t, _ = to_device(anchors, np.float32, device)
+    if t.dim() != 2 or t.shape[1] != 4:
+        raise ValueError("default boxes must have shape (A, 4), got %s" % (tuple(t.shape),))
+    return None, t, int(t.shape[0]), t
+
+
+def match_encode_batch(anchors, gt_boxes, gt_count, gt_labels=None, max_size=512.0,
+                       iou_threshold=0.5, y_true=False, return_match=False, context=None):
+    """Training targets for a batch.
+
+    anchors: AnchorGrid (on the fly) or (A,4) [cx,cy,w,h]; gt_boxes (B,G,4) normalised
+    corners, zero padded; gt_count (B,) boxes per image, each in [1, G]; gt_labels (B,G)
+    (default: all ones, as reference utils/datasets.py:130).
+    Returns (conf (B,A), locs (B,A,4)), or y_true (B,A,6) = [one_hot(conf), locs] when
+    y_true=True (reference utils/datasets.py:155-159); with return_match also
+    (match_idx (B,A) int32, match_iou (B,A)) after the forced best-anchor scatter.
+    Outputs are torch CUDA tensors when the inputs were torch tensors, numpy otherwise.
+    """
+    torch = require_gpu()
+    device = torch.cuda.current_device()
+    ctx = context or default_context(device)
+    counts_host = np.asarray(gt_count.cpu() if isinstance(gt_count, torch.Tensor) else gt_count)
+    boxes, family = to_device(gt_boxes, np.float32, device)
+    if boxes.dim() != 3 or boxes.shape[2] != 4:
+        raise ValueError("gt_boxes must have shape (B, G, 4), got %s" % (tuple(boxes.shape),))
+    B, G = int(boxes.shape[0]), int(boxes.shape[1])
+    if counts_host.shape != (B,):
+        raise ValueError("gt_count must have shape (%d,), got %s" % (B, counts_host.shape))
+    if B == 0 or G == 0 or counts_host.min() < 1 or counts_host.max() > G:
+        # the reference drops images without boxes before this call (utils/datasets.py:84-96)
+        raise ValueError("every image needs between 1 and %d ground-truth boxes" % G)
+    counts, _ = to_device(counts_host.astype(np.int32), np.int32, device)
+    if gt_labels is None:
+        labels = torch.ones((B, G), dtype=torch.float32, device=boxes.device)
+    else:
+        labels, _ = to_device(gt_labels, np.float32, device)
+        if tuple(labels.shape) != (B, G):
+            raise ValueError("gt_labels must have shape (%d, %d)" % (B, G))
+    geom, anc, A, _keep = _anchor_source(anchors, device)
+    lib = ctx.lib
+    if y_true:
+        out = torch.empty((B, A, 6), dtype=torch.float32, device=boxes.device)
+        _lib.check(lib.ssdbox_match_encode_ytrue(
+            ctx.handle, geom, _ptr(anc), A, _ptr(boxes), _ptr(labels), _ptr(counts), B, G,
+            float(max_size), float(iou_threshold), _ptr(out)))
+        return from_device(out, family)
+    conf = torch.empty((B, A), dtype=torch.float32, device=boxes.device)
+    locs = torch.empty((B, A, 4), dtype=torch.float32, device=boxes.device)
+    midx = torch.empty((B, A), dtype=torch.int32, device=boxes.device) if return_match else None
+    miou = torch.empty((B, A), dtype=torch.float32, device=boxes.device) if return_match else None
+    _lib.check(lib.ssdbox_match_encode(
+        ctx.handle, geom, _ptr(anc), A, _ptr(boxes), _ptr(labels), _ptr(counts), B, G,
+        float(max_size), float(iou_threshold), _ptr(conf), _ptr(locs), _ptr(midx), _ptr(miou)))
+    res = (from_device(conf, family), from_device(locs, family))
+    if return_match:
+        res += (from_device(midx, family), from_device(miou, family))
+    return res
+
+
+def decode_nms_batch(anchors, y_pred, score_threshold, nms_threshold=0.45, limit=1000,
+                     img_wh=None, context=None):
+    """Detections for a batch of head outputs.
+
+    y_pred (B,A,6) = [softmax_bg, softmax_face, tx, ty, tw, th]; img_wh (B,2) original
+    (width, height) per image or None for normalised output.  Returns
+    (dets (B,limit,6) rows [1, score, xmin, ymin, xmax, ymax] in kept order and zero
+    after the count, keep_idx (B,limit) int32 anchor indices (-1 after the count),
+    count (B,) int32).
+    """
+    torch = require_gpu()
+    device = torch.cuda.current_device()
+    ctx = context or default_context(device)
+    y, family = to_device(y_pred, np.float32, device)
+    if y.dim() != 3 or y.shape[2] != 6:
+        raise ValueError("y_pred must have shape (B, A, 6), got %s" % (tuple(y.shape),))
+    B = int(y.shape[0])
+    geom, anc, A, _keep = _anchor_source(anchors, device)
+    if int(y.shape[1]) != A:
+        raise ValueError("y_pred has %d boxes per image, the anchors %d" % (int(y.shape[1]), A))
+    limit = int(limit)
+    wh = None
+    if img_wh is not None:
+        wh, _ = to_device(img_wh, np.float32, device)
+        if tuple(wh.shape) != (B, 2):
+            raise ValueError("img_wh must have shape (%d, 2)" % B)
+    dets = torch.empty((B, max(limit, 1), 6), dtype=torch.float32, device=y.device)
+    keep = torch.empty((B, max(limit, 1)), dtype=torch.int32, device=y.device)
+    count = torch.empty((B,), dtype=torch.int32, device=y.device)
+    if B == 0:
+        return from_device(dets, family), from_device(keep, family), from_device(count, family)
+    _lib.check(ctx.lib.ssdbox_decode_nms(
+        ctx.handle, geom, _ptr(anc), A, _ptr(y), B, float(score_threshold), float(nms_threshold),
+        limit, _ptr(wh), _ptr(dets), _ptr(keep), _ptr(count)))
+    return from_device(dets, family), from_device(keep, family), from_device(count, family)

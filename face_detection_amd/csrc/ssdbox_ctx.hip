@@ -1,0 +1,330 @@
+// Context, error reporting, scratch management, stage timing and the anchor geometry
+// (host side of reference utils/anchor_utils.py:6-62).
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "ssdbox_internal.h"
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" int ssdbox_version(void) { return 100; }
+
+extern "C" const char *ssdbox_last_error(void) { return g_err; }
+
+// --------------------------------------------------------------------------- scratch
+// Grows *ptr to hold `need` elements.  A grown (or first) buffer is zero-filled when
+// `zero` is set; callers rely on that for the counters that kernels keep at zero.
+int ensure_buffer(void **ptr, size_t *cap, size_t need, size_t elem_size, bool zero,
+                  hipStream_t stream)
+{
+    if (need <= *cap && *ptr != nullptr) return SSDBOX_OK;
+    if (*ptr != nullptr) {
+        SSD_CHECK_HIP(hipStreamSynchronize(stream));
+        SSD_CHECK_HIP(hipFree(*ptr));
+        *ptr = nullptr;
+        *cap = 0;
+    }
+    size_t want = need + need / 4 + 64;
+    hipError_t e = hipMalloc(ptr, want * elem_size);
+    if (e != hipSuccess) {
+        *ptr = nullptr;
+        set_error("hipMalloc of %zu bytes failed: %s", want * elem_size, hipGetErrorString(e));
+        return SSDBOX_ERR_NOMEM;
+    }
+    *cap = want;
+    if (zero) SSD_CHECK_HIP(hipMemsetAsync(*ptr, 0, want * elem_size, stream));
+    return SSDBOX_OK;
+}
+
+// ----------------------------------------------------------------------------- timing
+StageTimer::StageTimer(ssdbox_ctx *c, int stage) : ctx(c)
+{
+    if (!ctx->timing) return;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    for (int i = 0; i < 2; ++i) {
+        if (!ctx->event_pool.empty()) {
+            ev[i] = ctx->event_pool.back();
+            ctx->event_pool.pop_back();
+        } else if (hipEventCreate(&ev[i]) != hipSuccess) {
+            ev[i] = nullptr;
+        }
+    }
+    if (ev[0] == nullptr || ev[1] == nullptr) return;
+    (void)hipEventRecord(ev[0], ctx->stream);
+    stop = ev[1];
+    ctx->records.push_back({stage, ev[0], ev[1]});
+}
+
+StageTimer::~StageTimer()
+{
+    if (stop != nullptr) (void)hipEventRecord(stop, ctx->stream);
+}
+
+// ---------------------------------------------------------------------------- context
+extern "C" int ssdbox_ctx_create(int device, void *stream, ssdbox_ctx **out)
+{
+    SSD_REQUIRE(out != nullptr, "ssdbox_ctx_create: out is NULL");
+    *out = nullptr;
+    int n_dev = 0;
+    SSD_CHECK_HIP(hipGetDeviceCount(&n_dev));
+    SSD_REQUIRE(device >= 0 && device < n_dev, "ssdbox_ctx_create: device %d of %d", device, n_dev);
+    DeviceGuard guard(device);
+    hipDeviceProp_t prop;
+    SSD_CHECK_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("libssdbox is built for gfx950 only; device %d is %s", device, prop.gcnArchName);
+        return SSDBOX_ERR_UNSUPPORTED;
+    }
+    ssdbox_ctx *ctx = new ssdbox_ctx();
+    ctx->device = device;
+    ctx->owns_stream = (stream == nullptr);
+    ctx->timing = false;
+    if (ctx->owns_stream) {
+        hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete ctx;
+            set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
+            return SSDBOX_ERR_HIP;
+        }
+    } else {
+        ctx->stream = (hipStream_t)stream;
+    }
+    *out = ctx;
+    return SSDBOX_OK;
+}
+
+extern "C" int ssdbox_ctx_destroy(ssdbox_ctx *ctx)
+{
+    if (ctx == nullptr) return SSDBOX_OK;
+    DeviceGuard guard(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &r : ctx->records) {
+        (void)hipEventDestroy(r.start);
+        (void)hipEventDestroy(r.stop);
+    }
+    for (auto &e : ctx->event_pool) (void)hipEventDestroy(e);
+    void *bufs[] = {ctx->gkey, ctx->cand, ctx->cand_count, ctx->sboxes, ctx->sscores,
+                    ctx->sidx, ctx->keff, ctx->mask, ctx->selftest_out};
+    for (void *b : bufs)
+        if (b != nullptr) (void)hipFree(b);
+    if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return SSDBOX_OK;
+}
+
+extern "C" int ssdbox_ctx_set_stream(ssdbox_ctx *ctx, void *stream)
+{
+    SSD_REQUIRE(ctx != nullptr, "ssdbox_ctx_set_stream: ctx is NULL");
+    DeviceGuard guard(ctx->device);
+    SSD_CHECK_HIP(hipStreamSynchronize(ctx->stream));     // scratch is tied to stream order
+    if (ctx->owns_stream) {
+        SSD_CHECK_HIP(hipStreamDestroy(ctx->stream));
+        ctx->owns_stream = false;
+    }
+    if (stream == nullptr) {
+        SSD_CHECK_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        ctx->owns_stream = true;
+    } else {
+        ctx->stream = (hipStream_t)stream;
+    }
+    return SSDBOX_OK;
+}
+
+extern "C" int ssdbox_ctx_synchronize(ssdbox_ctx *ctx)
+{
+    SSD_REQUIRE(ctx != nullptr, "ssdbox_ctx_synchronize: ctx is NULL");
+    DeviceGuard guard(ctx->device);
+    SSD_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    return SSDBOX_OK;
+}
+
+extern "C" int ssdbox_ctx_set_timing(ssdbox_ctx *ctx, int enabled)
+{
+    SSD_REQUIRE(ctx != nullptr, "ssdbox_ctx_set_timing: ctx is NULL");
+    ctx->timing = (enabled != 0);
+    return SSDBOX_OK;
+}
+
+extern "C" int ssdbox_ctx_collect_timing(ssdbox_ctx *ctx, float *ms, int32_t *launches)
+{
+    SSD_REQUIRE(ctx != nullptr && ms != nullptr && launches != nullptr,
+                "ssdbox_ctx_collect_timing: NULL argument");
+    DeviceGuard guard(ctx->device);
+    for (int s = 0; s < SSDBOX_NUM_STAGES; ++s) {
+        ms[s] = 0.0f;
+        launches[s] = 0;
+    }
+    SSD_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    for (auto &r : ctx->records) {
+        float t = 0.0f;
+        SSD_CHECK_HIP(hipEventElapsedTime(&t, r.start, r.stop));
+        ms[r.stage] += t;
+        launches[r.stage] += 1;
+        ctx->event_pool.push_back(r.start);
+        ctx->event_pool.push_back(r.stop);
+    }
+    ctx->records.clear();
+    return SSDBOX_OK;
+}
+
+// --------------------------------------------------------------------------- geometry
+extern "C" int ssdbox_geom_create(int device, int img_width, int img_height, int n_layers,
+                                  const int32_t *steps, const double *scales,
+                                  const int32_t *ratio_counts, const double *ratios_flat,
+                                  int two_boxes_for_ar1, double offsets, ssdbox_geom **out)
+{
+    SSD_REQUIRE(out != nullptr, "ssdbox_geom_create: out is NULL");
+    *out = nullptr;
+    SSD_REQUIRE(steps && scales && ratio_counts && ratios_flat, "ssdbox_geom_create: NULL table");
+    SSD_REQUIRE(n_layers >= 1 && n_layers <= SSDBOX_MAX_LAYERS,
+                "ssdbox_geom_create: n_layers %d outside [1, %d]", n_layers, SSDBOX_MAX_LAYERS);
+    SSD_REQUIRE(img_width > 0 && img_height > 0, "ssdbox_geom_create: image %dx%d", img_width,
+                img_height);
+
+    GeomDev g;
+    memset(&g, 0, sizeof(g));
+    g.n_layers = n_layers;
+    std::vector<float> cx, cy;
+    long long total = 0;
+    int tiles = 0;
+    const double *ratios = ratios_flat;
+    for (int m = 0; m < n_layers; ++m) {
+        SSD_REQUIRE(steps[m] > 0, "ssdbox_geom_create: steps[%d] = %d", m, steps[m]);
+        LayerDev &L = g.layer[m];
+        L.fm_w = img_width / steps[m];          // integer floor, anchor_utils.py:29-30
+        L.fm_h = img_height / steps[m];
+        int nb = 0;
+        for (int r = 0; r < ratio_counts[m]; ++r) {
+            double ratio = ratios[r];
+            double w[2], h[2];
+            int n = 0;
+            if (ratio == 1.0) {                 // anchor_utils.py:36-49
+                w[n] = scales[m];
+                h[n] = scales[m];
+                ++n;
+                if (two_boxes_for_ar1) {
+                    double s = sqrt(scales[m] * scales[m + 1]);
+                    w[n] = s;
+                    h[n] = s;
+                    ++n;
+                }
+            } else {                            // anchor_utils.py:50-57
+                double root = sqrt(ratio);
+                w[n] = scales[m] * root;
+                h[n] = scales[m] / root;
+                ++n;
+            }
+            for (int q = 0; q < n; ++q) {
+                SSD_REQUIRE(nb < SSDBOX_MAX_BOXES_PER_CELL,
+                            "ssdbox_geom_create: layer %d has more than %d boxes per cell", m,
+                            SSDBOX_MAX_BOXES_PER_CELL);
+                // float64 -> float32 once (anchor_utils.py:59), then clip (:60)
+                L.bw[nb] = fminf(fmaxf((float)w[q], 0.0f), 1.0f);
+                L.bh[nb] = fminf(fmaxf((float)h[q], 0.0f), 1.0f);
+                ++nb;
+            }
+        }
+        ratios += ratio_counts[m];
+        L.n_box = nb;
+        L.anchor_base = (int)total;
+        L.row_anchors = L.fm_w * nb;
+        total += (long long)L.fm_w * L.fm_h * nb;
+        SSD_REQUIRE(total < (1ll << 30), "ssdbox_geom_create: more than 2^30 anchors");
+        L.wmax = 0.0f;
+        L.hmax = 0.0f;
+        for (int k = 0; k < nb; ++k) {
+            L.wmax = fmaxf(L.wmax, L.bw[k]);
+            L.hmax = fmaxf(L.hmax, L.bh[k]);
+        }
+        L.tiles_x = (L.row_anchors + kTileCols - 1) / kTileCols;
+        L.tiles_y = (L.fm_h + kTileRows - 1) / kTileRows;
+        L.tile_base = tiles;
+        tiles += L.tiles_x * L.tiles_y;
+        L.cx_off = (int)cx.size();
+        L.cy_off = (int)cy.size();
+        for (int j = 0; j < L.fm_w; ++j)        // anchor_utils.py:32
+            cx.push_back(fminf(fmaxf((float)((j + offsets) / L.fm_w), 0.0f), 1.0f));
+        for (int i = 0; i < L.fm_h; ++i)        // anchor_utils.py:33
+            cy.push_back(fminf(fmaxf((float)((i + offsets) / L.fm_h), 0.0f), 1.0f));
+    }
+    g.num_anchors = (int)total;
+    g.n_tiles = tiles;
+
+    ssdbox_geom *geom = new ssdbox_geom();
+    geom->device = device;
+    geom->host = g;
+    geom->d_geom = nullptr;
+    geom->d_cx = nullptr;
+    geom->d_cy = nullptr;
+    if (device < 0) {           // host-only handle: layer table and counts, no kernels
+        *out = geom;
+        return SSDBOX_OK;
+    }
+    int n_dev = 0;
+    hipError_t e0 = hipGetDeviceCount(&n_dev);
+    if (e0 != hipSuccess || device >= n_dev) {
+        delete geom;
+        set_error("ssdbox_geom_create: device %d not available (%s)", device,
+                  e0 != hipSuccess ? hipGetErrorString(e0) : "index out of range");
+        return e0 != hipSuccess ? SSDBOX_ERR_HIP : SSDBOX_ERR_INVALID;
+    }
+    DeviceGuard guard(device);
+    size_t ncx = cx.size() ? cx.size() : 1, ncy = cy.size() ? cy.size() : 1;
+    hipError_t e = hipMalloc((void **)&geom->d_geom, sizeof(GeomDev));
+    if (e == hipSuccess) e = hipMalloc((void **)&geom->d_cx, ncx * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&geom->d_cy, ncy * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(geom->d_geom, &g, sizeof(GeomDev), hipMemcpyHostToDevice);
+    if (e == hipSuccess && !cx.empty())
+        e = hipMemcpy(geom->d_cx, cx.data(), cx.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess && !cy.empty())
+        e = hipMemcpy(geom->d_cy, cy.data(), cy.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        set_error("ssdbox_geom_create: device upload failed: %s", hipGetErrorString(e));
+        ssdbox_geom_destroy(geom);
+        return SSDBOX_ERR_HIP;
+    }
+    *out = geom;
+    return SSDBOX_OK;
+}
+
+extern "C" int ssdbox_geom_destroy(ssdbox_geom *geom)
+{
+    if (geom == nullptr) return SSDBOX_OK;
+    if (geom->device < 0) {
+        delete geom;
+        return SSDBOX_OK;
+    }
+    DeviceGuard guard(geom->device);
+    if (geom->d_geom) (void)hipFree(geom->d_geom);
+    if (geom->d_cx) (void)hipFree(geom->d_cx);
+    if (geom->d_cy) (void)hipFree(geom->d_cy);
+    delete geom;
+    return SSDBOX_OK;
+}
+
+extern "C" int64_t ssdbox_geom_num_anchors(const ssdbox_geom *geom)
+{
+    return geom ? (int64_t)geom->host.num_anchors : -1;
+}
+
+extern "C" int ssdbox_geom_layers(const ssdbox_geom *geom, int32_t *fm_w, int32_t *fm_h,
+                                  int32_t *n_box)
+{
+    if (geom == nullptr) return SSDBOX_ERR_INVALID;
+    for (int m = 0; m < geom->host.n_layers; ++m) {
+        if (fm_w) fm_w[m] = geom->host.layer[m].fm_w;
+        if (fm_h) fm_h[m] = geom->host.layer[m].fm_h;
+        if (n_box) n_box[m] = geom->host.layer[m].n_box;
+    }
+    return geom->host.n_layers;
+}

@@ -1,0 +1,286 @@
+// Internal definitions shared by the libssdbox translation units (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "ssdbox.h"
+
+// ---------------------------------------------------------------------------------------
+// Anchor geometry as the kernels see it.  One LayerDev per predictor layer; the per-column
+// and per-row centre tables (float32, already clipped) live in device memory because they
+// are the only part whose size grows with the image (sum of fm_w + fm_h floats).
+// ---------------------------------------------------------------------------------------
+constexpr int kTileRows = 8;       // match kernel: feature-map rows per workgroup tile
+constexpr int kTileCols = 32;      // match kernel: anchor columns (cell * n_box + k) per tile
+constexpr int kBlock = 256;
+
+struct LayerDev {
+    int fm_w, fm_h, n_box;
+    int anchor_base;               // index of the layer's first anchor
+    int row_anchors;               // fm_w * n_box
+    int tiles_x, tiles_y, tile_base;
+    int cx_off, cy_off;            // offsets of this layer in the centre tables
+    float wmax, hmax;              // largest clipped box width / height of the layer
+    float bw[SSDBOX_MAX_BOXES_PER_CELL];
+    float bh[SSDBOX_MAX_BOXES_PER_CELL];
+};
+
+struct GeomDev {
+    int n_layers;
+    int num_anchors;
+    int n_tiles;
+    int pad_;
+    LayerDev layer[SSDBOX_MAX_LAYERS];
+};
+
+struct ssdbox_geom {
+    int device;
+    GeomDev host;                  // host copy of what d_geom points to
+    GeomDev *d_geom;
+    float *d_cx;                   // concatenated per-layer column centres
+    float *d_cy;                   // concatenated per-layer row centres
+};
+
+// ---------------------------------------------------------------------------------------
+// Context: stream, scratch, optional per-stage event timing.
+// ---------------------------------------------------------------------------------------
+struct TimingRecord {
+    int stage;
+    hipEvent_t start, stop;
+};
+
+struct ssdbox_ctx {
+    int device;
+    hipStream_t stream;
+    bool owns_stream;
+    bool timing;
+    std::vector<TimingRecord> records;
+    std::vector<hipEvent_t> event_pool;
+
+    // match scratch: packed (iou bits, ~anchor) best-anchor key per (image, GT); all zero
+    // between calls (the fix-up kernel clears what it read).
+    unsigned long long *gkey;
+    size_t gkey_cap;               // entries
+    bool gkey_dirty;
+
+    // detection scratch
+    unsigned long long *cand;      // (batch, N) candidate keys
+    size_t cand_cap;
+    int *cand_count;               // (batch); zero between calls
+    size_t count_cap;
+    bool count_dirty;
+    float4 *sboxes;                // (batch, LIMIT) decoded boxes in rank order
+    float *sscores;
+    int *sidx;
+    int *keff;                     // (batch) effective K per image
+    unsigned long long *mask;      // (batch, LIMIT, LIMIT/64) suppression bits
+    size_t det_cap;                // images
+    int *selftest_out;
+};
+
+void set_error(const char *fmt, ...);
+
+#define SSD_CHECK_HIP(expr)                                                              \
+    do {                                                                                 \
+        hipError_t e_ = (expr);                                                          \
+        if (e_ != hipSuccess) {                                                          \
+            set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__,   \
+                      __LINE__);                                                         \
+            return SSDBOX_ERR_HIP;                                                       \
+        }                                                                                \
+    } while (0)
+
+#define SSD_REQUIRE(cond, ...)                                                           \
+    do {                                                                                 \
+        if (!(cond)) {                                                                   \
+            set_error(__VA_ARGS__);                                                      \
+            return SSDBOX_ERR_INVALID;                                                   \
+        }                                                                                \
+    } while (0)
+
+// Makes ctx->device current for the scope and restores the caller's device afterwards.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) {
+            switched = (hipSetDevice(dev) == hipSuccess);
+        }
+    }
+    ~DeviceGuard()
+    {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
+
+// Brackets one kernel launch with events when timing is on.
+struct StageTimer {
+    ssdbox_ctx *ctx;
+    hipEvent_t stop = nullptr;
+    StageTimer(ssdbox_ctx *c, int stage);
+    ~StageTimer();
+};
+
+int ensure_buffer(void **ptr, size_t *cap, size_t need, size_t elem_size, bool zero,
+                  hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------
+// Device helpers.
+// ---------------------------------------------------------------------------------------
+#define SSD_DEV __device__ __forceinline__
+
+SSD_DEV uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
+SSD_DEV float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+
+// clip_by_value(x, 0, hi) of reference utils/box_utils.py:15 for hi >= 0.
+SSD_DEV float clip0(float x, float hi) { return fminf(fmaxf(x, 0.0f), hi); }
+
+// Natural log and exp as fixed sequences of IEEE float32 operations (Cephes single
+// precision): every + - * / below rounds once (the library is built with
+// -ffp-contract=off), so any implementation of the same sequence returns the same bits.
+SSD_DEV float ssd_logf(float x)
+{
+    if (x != x) return x;
+    if (x < 0.0f) return u2f(0x7FC00000u);
+    if (x == 0.0f) return u2f(0xFF800000u);
+    uint32_t u = f2u(x);
+    if (u == 0x7F800000u) return x;
+    int e = 0;
+    if ((u >> 23) == 0) {
+        x = x * 8388608.0f;
+        u = f2u(x);
+        e = -23;
+    }
+    e += (int)(u >> 23) - 126;
+    float m = u2f((u & 0x007FFFFFu) | 0x3F000000u);
+    if (m < 0.707106781186547524f) {
+        e -= 1;
+        m = m + m - 1.0f;
+    } else {
+        m = m - 1.0f;
+    }
+    float z = m * m;
+    float y = 7.0376836292E-2f;
+    y = y * m + -1.1514610310E-1f;
+    y = y * m + 1.1676998740E-1f;
+    y = y * m + -1.2420140846E-1f;
+    y = y * m + 1.4249322787E-1f;
+    y = y * m + -1.6668057665E-1f;
+    y = y * m + 2.0000714765E-1f;
+    y = y * m + -2.4999993993E-1f;
+    y = y * m + 3.3333331174E-1f;
+    y = y * m * z;
+    float fe = (float)e;
+    if (e != 0) y = y + -2.12194440e-4f * fe;
+    y = y + -0.5f * z;
+    z = m + y;
+    if (e != 0) z = z + 0.693359375f * fe;
+    return z;
+}
+
+SSD_DEV float ssd_expf(float x)
+{
+    if (x != x) return x;
+    if (x > 88.72283905206835f) return u2f(0x7F800000u);
+    if (x < -103.278929903431851103f) return 0.0f;
+    float z = floorf(1.44269504088896341f * x + 0.5f);
+    x = x - z * 0.693359375f;
+    x = x - z * -2.12194440e-4f;
+    int n = (int)z;
+    z = x * x;
+    float p = 1.9875691500E-4f;
+    p = p * x + 1.3981999507E-3f;
+    p = p * x + 8.3334519073E-3f;
+    p = p * x + 4.1665795894E-2f;
+    p = p * x + 1.6666665459E-1f;
+    p = p * x + 5.0000001201E-1f;
+    z = p * z + x + 1.0f;
+    if (n > 127) {
+        z = z * u2f((uint32_t)(100 + 127) << 23);
+        n -= 100;
+    } else if (n < -126) {
+        z = z * u2f((uint32_t)(-100 + 127) << 23);
+        n += 100;
+    }
+    return z * u2f((uint32_t)(n + 127) << 23);
+}
+
+// Anchor a of a geometry: [cx, cy, w, h] (reference utils/anchor_utils.py:28-60 order:
+// layer, row, column, box).
+SSD_DEV float4 geom_anchor(const GeomDev *__restrict__ g, const float *__restrict__ cx_tab,
+                           const float *__restrict__ cy_tab, int a)
+{
+    int m = 0;
+    while (m + 1 < g->n_layers && a >= g->layer[m + 1].anchor_base) ++m;
+    const LayerDev &L = g->layer[m];
+    int r = a - L.anchor_base;
+    int i = r / L.row_anchors;
+    int c = r - i * L.row_anchors;
+    int j = c / L.n_box;
+    int k = c - j * L.n_box;
+    return make_float4(cx_tab[L.cx_off + j], cy_tab[L.cy_off + i], L.bw[k], L.bh[k]);
+}
+
+// encode of reference utils/box_utils.py:101-123 for one anchor [cx,cy,w,h] and one corner
+// box; vc / vs are variance[0] / variance[1].
+SSD_DEV float4 encode_one(float4 anc, float4 box, float vc, float vs)
+{
+    float cx = (box.x + box.z) / 2.0f;
+    float cy = (box.y + box.w) / 2.0f;
+    float w = box.z - box.x;
+    float h = box.w - box.y;
+    float4 t;
+    t.x = (cx - anc.x) / (anc.z * vc);
+    t.y = (cy - anc.y) / (anc.w * vc);
+    t.z = ssd_logf(w / anc.z) / vs;
+    t.w = ssd_logf(h / anc.w) / vs;
+    return t;
+}
+
+// decode of reference utils/box_utils.py:126-147 for one anchor and one offset row.
+SSD_DEV float4 decode_one(float4 anc, float4 l, float vc, float vs)
+{
+    float cx = l.x * vc * anc.z + anc.x;
+    float cy = l.y * vc * anc.w + anc.y;
+    float w = ssd_expf(l.z * vs) * anc.z;
+    float h = ssd_expf(l.w * vs) * anc.w;
+    float hw = w / 2.0f, hh = h / 2.0f;
+    return make_float4(cx - hw, cy - hh, cx + hw, cy + hh);
+}
+
+// Maximum over the 64 lanes of a wave of a value >= 0 (identity 0), returned in every lane.
+SSD_DEV float wave_max_nonneg(float v)
+{
+    int x = (int)f2u(v);
+    // row_shr 1,2,4,8 inside each row of 16 lanes, then the two cross-row broadcasts; lanes
+    // without a source keep the identity 0.  Non-negative floats order like their bits.
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false));
+    return u2f((uint32_t)__builtin_amdgcn_readlane(x, 63));
+}
+
+SSD_DEV int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// Rank key of a score: larger key = ranks earlier.  -0 is folded into +0 (they compare
+// equal, so order falls to the index), NaN ranks last.
+SSD_DEV uint32_t score_key(float s)
+{
+    if (s != s) return 0u;
+    s = s + 0.0f;
+    uint32_t u = f2u(s);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+SSD_DEV unsigned long long rank_key(float s, uint32_t index)
+{
+    return ((unsigned long long)score_key(s) << 32) | (unsigned long long)(0xFFFFFFFFu - index);
+}

@@ -97,8 +97,9 @@ def _softmax2(logit_face):
 
 
 def make_head_outputs(rng, config, gt_boxes, gt_counts, n_ties=64, dup_per_gt=5):
-    """y_pred (B,A,6) f32: offsets ~ N(0,1); face logit ~ N(-4,2) through a 2-class
-    softmax (about 2-3 % above 0.05); around every GT `dup_per_gt` anchors get a high
+    """y_pred (B,A,6) f32: offsets ~ N(0,1); face-minus-background logit ~ N(-4, 0.55)
+    through a 2-class softmax, which puts 2-3 % of the anchors above the reference's 0.05
+    confidence threshold (config.py:47); around every GT `dup_per_gt` anchors get a high
     score and offsets that decode close to the GT (so NMS has clusters to suppress);
     `n_ties` random anchors per image get the exact score 1.0f.
     """
@@ -106,7 +107,7 @@ def make_head_outputs(rng, config, gt_boxes, gt_counts, n_ties=64, dup_per_gt=5)
     B = gt_boxes.shape[0]
     y = np.empty((B, A, 6), F32)
     y[:, :, 2:] = rng.standard_normal((B, A, 4), dtype=np.float32)
-    y[:, :, :2] = _softmax2(rng.normal(-4.0, 2.0, (B, A))).astype(F32)
+    y[:, :, :2] = _softmax2(rng.normal(-4.0, 0.55, (B, A))).astype(F32)
     scale_of_layer = np.array([math.sqrt(sh[0][0] * sh[0][1]) for (_, _, sh, _) in layers])
     for b in range(B):
         for g in range(int(gt_counts[b])):

@@ -1,0 +1,166 @@
+/*
+ * libssdbox -- C ABI of the MI355X (gfx950) SSD box pipeline.
+ *
+ * The reference (rao1140427950/face_detection) has no FFI layer: its boundary for this
+ * path is the Python module surface of utils/anchor_utils.py and utils/box_utils.py.  Each
+ * entry point below names the reference function (file:line) it stands in for.  All
+ * pointers named d_* are DEVICE pointers on the context's GPU; everything else is host
+ * memory.  All tensors are dense, row-major, float32 unless stated.  Every call returns 0
+ * on success or a negative SSDBOX_ERR_* code and never throws or aborts across the ABI;
+ * ssdbox_last_error() returns the message of the calling thread's most recent failure.
+ *
+ * Work is enqueued on the context's stream and is asynchronous with respect to the host
+ * unless a function says otherwise.  A context (stream + scratch buffers) must not be used
+ * by two threads at once; create one per thread (the reference calls this path from six
+ * tf.data worker threads, utils/datasets.py:42,179-180).  Geometry handles are immutable
+ * and may be shared between contexts of the same device.
+ */
+#ifndef SSDBOX_H
+#define SSDBOX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSDBOX_OK                 0
+#define SSDBOX_ERR_INVALID       (-1)  /* bad argument (null pointer, size, threshold)      */
+#define SSDBOX_ERR_HIP           (-2)  /* a HIP runtime call or kernel launch failed        */
+#define SSDBOX_ERR_NOMEM         (-3)  /* scratch allocation failed                         */
+#define SSDBOX_ERR_UNSUPPORTED   (-4)  /* valid request outside what the kernels implement  */
+
+#define SSDBOX_MAX_LAYERS          8   /* predictor layers in one anchor geometry           */
+#define SSDBOX_MAX_BOXES_PER_CELL 16   /* boxes per feature-map cell                        */
+#define SSDBOX_MAX_NMS_LIMIT    1024   /* largest effective pre-NMS top-k, min(limit, N)    */
+#define SSDBOX_MAX_GT           4096   /* largest ground-truth count per image              */
+
+typedef struct ssdbox_ctx ssdbox_ctx;
+typedef struct ssdbox_geom ssdbox_geom;
+
+/* Kernel stages whose device time a context can accumulate (ssdbox_ctx_set_timing). */
+enum {
+    SSDBOX_STAGE_MATCH = 0,      /* anchors x GT IoU, match, encode (one launch per batch)   */
+    SSDBOX_STAGE_FORCE = 1,      /* forced best-anchor-per-GT fix-up                         */
+    SSDBOX_STAGE_SELECT = 2,     /* score threshold + candidate compaction over y_pred       */
+    SSDBOX_STAGE_TOPK = 3,       /* per-image top-k select, sort, decode of survivors        */
+    SSDBOX_STAGE_NMS_MASK = 4,   /* K x K suppression bit matrix                             */
+    SSDBOX_STAGE_NMS_SCAN = 5,   /* greedy scan + detection assembly                         */
+    SSDBOX_STAGE_ELEMENTWISE = 6,
+    SSDBOX_NUM_STAGES = 7
+};
+
+int ssdbox_version(void);
+const char *ssdbox_last_error(void);
+
+/* ---- context ---------------------------------------------------------------------- */
+/* stream: a hipStream_t owned by the caller (e.g. torch's current stream), or NULL to let
+ * the context create and own one. */
+int ssdbox_ctx_create(int device, void *stream, ssdbox_ctx **out);
+int ssdbox_ctx_destroy(ssdbox_ctx *ctx);
+int ssdbox_ctx_set_stream(ssdbox_ctx *ctx, void *stream);
+int ssdbox_ctx_synchronize(ssdbox_ctx *ctx);            /* blocks the host */
+/* Per-stage device timing with HIP events on the context's stream.  collect() blocks
+ * until the recorded launches finish, adds them up into ms[SSDBOX_NUM_STAGES] and
+ * launches[SSDBOX_NUM_STAGES] and clears the records. */
+int ssdbox_ctx_set_timing(ssdbox_ctx *ctx, int enabled);
+int ssdbox_ctx_collect_timing(ssdbox_ctx *ctx, float *ms, int32_t *launches);
+
+/* ---- anchor geometry: utils/anchor_utils.py:6-62 ----------------------------------- */
+/* Builds the feature-map geometry generate_anchors(config) iterates over, with the same
+ * float64 arithmetic (centre = (index + offsets) / fm_size, sqrt of ratios and of
+ * s_m * s_{m+1}) rounded once to float32 and clipped to [0,1].  Kernels given a geometry
+ * generate anchors on the fly; nothing of size A is stored.
+ *   steps[n_layers], scales[n_layers + 1], ratio_counts[n_layers],
+ *   ratios_flat[sum(ratio_counts)] (the per-layer ratio lists back to back). */
+int ssdbox_geom_create(int device, int img_width, int img_height, int n_layers,
+                       const int32_t *steps, const double *scales,
+                       const int32_t *ratio_counts, const double *ratios_flat,
+                       int two_boxes_for_ar1, double offsets, ssdbox_geom **out);
+int ssdbox_geom_destroy(ssdbox_geom *geom);
+int64_t ssdbox_geom_num_anchors(const ssdbox_geom *geom);
+/* Layer table for callers: fm_w/fm_h/n_box[n_layers] (any may be NULL); returns n_layers. */
+int ssdbox_geom_layers(const ssdbox_geom *geom, int32_t *fm_w, int32_t *fm_h, int32_t *n_box);
+/* Materialises what generate_anchors returns: d_out (A,4) [cx, cy, w, h]. */
+int ssdbox_generate_anchors(ssdbox_ctx *ctx, const ssdbox_geom *geom, float *d_out);
+
+/* ---- training side: utils/box_utils.py:47-98 (compute_target), batched -------------- */
+/* For each of `batch` images: IoU of every anchor with the image's gt_count[b] boxes,
+ * best GT per anchor (first maximum), best anchor per GT (lowest index) forced onto that
+ * anchor in ascending GT order with IoU 1, conf = label of the matched GT where the IoU is
+ * not < iou_threshold else 0, locs = encode(anchor, matched GT) for every anchor.
+ * Anchors: pass geom (on the fly) or d_anchors (A,4) [cx,cy,w,h]; the other is NULL.
+ *   d_gt_boxes (batch,gmax,4) corners, d_gt_labels (batch,gmax), d_gt_count (batch) int32,
+ *   each count in [1, gmax].  Outputs: d_conf (batch,A), d_locs (batch,A,4); optional
+ *   (may be NULL) d_match_idx (batch,A) int32 and d_match_iou (batch,A): best_gt_idx /
+ *   best_gt_iou after the forced scatter (utils/box_utils.py:72-87).
+ * A count outside [1, gmax] is a caller error the kernels do not detect (the reference
+ * never calls this with zero boxes, utils/datasets.py:84-96); validate on the host. */
+int ssdbox_match_encode(ssdbox_ctx *ctx, const ssdbox_geom *geom, const float *d_anchors,
+                        int64_t num_anchors, const float *d_gt_boxes,
+                        const float *d_gt_labels, const int32_t *d_gt_count, int batch,
+                        int gmax, float max_size, float iou_threshold, float *d_conf,
+                        float *d_locs, int32_t *d_match_idx, float *d_match_iou);
+
+/* Same match, emitting the training-side consumer layout of utils/datasets.py:155-159
+ * directly: d_y_true (batch,A,6) = [one_hot(int(conf), 2), locs]. */
+int ssdbox_match_encode_ytrue(ssdbox_ctx *ctx, const ssdbox_geom *geom,
+                              const float *d_anchors, int64_t num_anchors,
+                              const float *d_gt_boxes, const float *d_gt_labels,
+                              const int32_t *d_gt_count, int batch, int gmax,
+                              float max_size, float iou_threshold, float *d_y_true);
+
+/* ---- inference side: inference.py:33-83, batched ------------------------------------ */
+/* d_y_pred (batch,A,6) = [softmax_bg, softmax_face, tx, ty, tw, th] (models/ssd.py:95-99).
+ * Per image: keep score = y[:,1] > score_threshold (strict), rank by (score desc, anchor
+ * index asc), take the first `limit`, decode those boxes (utils/box_utils.py:126-147),
+ * greedy NMS with suppression !(IoU <= nms_threshold) (utils/box_utils.py:205-222), then
+ * clip to [0,1] and scale x by img_wh[b][0], y by img_wh[b][1] (inference.py:73-77).
+ * Outputs: d_dets (batch,limit,6) rows [1, score, xmin, ymin, xmax, ymax] in kept order,
+ * zero rows after the count; d_keep_idx (batch,limit) int32 anchor index of each kept box
+ * (-1 after the count); d_count (batch) int32.  d_img_wh (batch,2) may be NULL (scale 1).
+ * limit must be in [1, SSDBOX_MAX_NMS_LIMIT]; nms_threshold must be < 1. */
+int ssdbox_decode_nms(ssdbox_ctx *ctx, const ssdbox_geom *geom, const float *d_anchors,
+                      int64_t num_anchors, const float *d_y_pred, int batch,
+                      float score_threshold, float nms_threshold, int limit,
+                      const float *d_img_wh, float *d_dets, int32_t *d_keep_idx,
+                      int32_t *d_count);
+
+/* utils/box_utils.py:184-222 (compute_nms) on caller-supplied boxes: d_boxes (n,4)
+ * corners, d_scores (n).  Writes the kept indices into the input arrays, in kept order,
+ * to d_keep (min(limit,n) int32) and their number to d_count (1 int32).  n == 0 yields
+ * count 0.  min(limit, n) must not exceed SSDBOX_MAX_NMS_LIMIT. */
+int ssdbox_compute_nms(ssdbox_ctx *ctx, const float *d_boxes, const float *d_scores,
+                       int64_t n, float nms_threshold, int limit, int32_t *d_keep,
+                       int32_t *d_count);
+
+/* ---- elementwise box math ----------------------------------------------------------- */
+/* utils/box_utils.py:4-18: d_top_left (n,2), d_bot_right (n,2) -> d_area (n). */
+int ssdbox_compute_area(ssdbox_ctx *ctx, const float *d_top_left, const float *d_bot_right,
+                        int64_t n, float max_size, float *d_area);
+/* utils/box_utils.py:21-44: corners (na,4),(nb,4) -> d_iou (na,nb). */
+int ssdbox_compute_iou(ssdbox_ctx *ctx, const float *d_boxes_a, int64_t na,
+                       const float *d_boxes_b, int64_t nb, float max_size, float *d_iou);
+/* utils/box_utils.py:101-123: d_boxes (rows,4) corners with rows a multiple of A (leading
+ * batch dims flattened; row r pairs with anchor r % A) -> d_locs (rows,4). */
+int ssdbox_encode(ssdbox_ctx *ctx, const ssdbox_geom *geom, const float *d_anchors,
+                  int64_t num_anchors, const float *d_boxes, int64_t rows, float v_center,
+                  float v_size, float *d_locs);
+/* utils/box_utils.py:126-147: d_locs (rows,4) -> d_boxes (rows,4) corners, no clipping. */
+int ssdbox_decode(ssdbox_ctx *ctx, const ssdbox_geom *geom, const float *d_anchors,
+                  int64_t num_anchors, const float *d_locs, int64_t rows, float v_center,
+                  float v_size, float *d_boxes);
+/* utils/box_utils.py:150-164 and :167-181 on (n,4) rows. */
+int ssdbox_corner_to_center(ssdbox_ctx *ctx, const float *d_in, int64_t n, float *d_out);
+int ssdbox_center_to_corner(ssdbox_ctx *ctx, const float *d_in, int64_t n, float *d_out);
+
+/* Device self-checks of the building blocks (wave reductions, exp/log against the values
+ * in expect_log/expect_exp for the host inputs x_log/x_exp, n each).  Blocks the host.
+ * Returns 0 when every check passes. */
+int ssdbox_selftest(ssdbox_ctx *ctx, const float *x_log, const float *expect_log,
+                    const float *x_exp, const float *expect_exp, int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSDBOX_H */

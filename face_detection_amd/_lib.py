@@ -35,9 +35,9 @@ _pd = ctypes.POINTER(ctypes.c_double)
 SIGNATURES = {
     "ssdbox_version": (_i, []),
     "ssdbox_last_error": (ctypes.c_char_p, []),
-    "ssdbox_ctx_create": (_i, [_i, _vp, ctypes.POINTER(_vp)]),
+    "ssdbox_ctx_create": (_i, [_i, _vp, _i, ctypes.POINTER(_vp)]),
     "ssdbox_ctx_destroy": (_i, [_vp]),
-    "ssdbox_ctx_set_stream": (_i, [_vp, _vp]),
+    "ssdbox_ctx_set_stream": (_i, [_vp, _vp, _i]),
     "ssdbox_ctx_synchronize": (_i, [_vp]),
     "ssdbox_ctx_set_timing": (_i, [_vp, _i]),
     "ssdbox_ctx_collect_timing": (_i, [_vp, _pf, _pi32]),

@@ -71,7 +71,7 @@ StageTimer::~StageTimer()
 }
 
 // ---------------------------------------------------------------------------- context
-extern "C" int ssdbox_ctx_create(int device, void *stream, ssdbox_ctx **out)
+extern "C" int ssdbox_ctx_create(int device, void *stream, int own_stream, ssdbox_ctx **out)
 {
     SSD_REQUIRE(out != nullptr, "ssdbox_ctx_create: out is NULL");
     *out = nullptr;
@@ -87,7 +87,7 @@ extern "C" int ssdbox_ctx_create(int device, void *stream, ssdbox_ctx **out)
     }
     ssdbox_ctx *ctx = new ssdbox_ctx();
     ctx->device = device;
-    ctx->owns_stream = (stream == nullptr);
+    ctx->owns_stream = (own_stream != 0);
     ctx->timing = false;
     if (ctx->owns_stream) {
         hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
@@ -122,7 +122,7 @@ extern "C" int ssdbox_ctx_destroy(ssdbox_ctx *ctx)
     return SSDBOX_OK;
 }
 
-extern "C" int ssdbox_ctx_set_stream(ssdbox_ctx *ctx, void *stream)
+extern "C" int ssdbox_ctx_set_stream(ssdbox_ctx *ctx, void *stream, int own_stream)
 {
     SSD_REQUIRE(ctx != nullptr, "ssdbox_ctx_set_stream: ctx is NULL");
     DeviceGuard guard(ctx->device);
@@ -131,7 +131,7 @@ extern "C" int ssdbox_ctx_set_stream(ssdbox_ctx *ctx, void *stream)
         SSD_CHECK_HIP(hipStreamDestroy(ctx->stream));
         ctx->owns_stream = false;
     }
-    if (stream == nullptr) {
+    if (own_stream != 0) {
         SSD_CHECK_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
         ctx->owns_stream = true;
     } else {

@@ -42,7 +42,7 @@ class Context:
         self.stream = stream
         handle = stream.cuda_stream if hasattr(stream, "cuda_stream") else int(stream)
         out = ctypes.c_void_p()
-        _lib.check(self.lib.ssdbox_ctx_create(self.device, ctypes.c_void_p(handle), ctypes.byref(out)))
+        _lib.check(self.lib.ssdbox_ctx_create(self.device, ctypes.c_void_p(handle), 0, ctypes.byref(out)))
         self.handle = out
 
     def close(self):

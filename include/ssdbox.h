@@ -54,11 +54,12 @@ int ssdbox_version(void);
 const char *ssdbox_last_error(void);
 
 /* ---- context ---------------------------------------------------------------------- */
-/* stream: a hipStream_t owned by the caller (e.g. torch's current stream), or NULL to let
- * the context create and own one. */
-int ssdbox_ctx_create(int device, void *stream, ssdbox_ctx **out);
+/* stream: a hipStream_t owned by the caller (e.g. torch's current stream; NULL is the
+ * device's default stream).  With own_stream != 0 the argument is ignored and the context
+ * creates and owns a non-blocking stream instead. */
+int ssdbox_ctx_create(int device, void *stream, int own_stream, ssdbox_ctx **out);
 int ssdbox_ctx_destroy(ssdbox_ctx *ctx);
-int ssdbox_ctx_set_stream(ssdbox_ctx *ctx, void *stream);
+int ssdbox_ctx_set_stream(ssdbox_ctx *ctx, void *stream, int own_stream);
 int ssdbox_ctx_synchronize(ssdbox_ctx *ctx);            /* blocks the host */
 /* Per-stage device timing with HIP events on the context's stream.  collect() blocks
  * until the recorded launches finish, adds them up into ms[SSDBOX_NUM_STAGES] and

@@ -1,0 +1,280 @@
+#!/usr/bin/env python3
+"""Benchmark of the SSD box pipeline on MI355X.
+
+A step = one pass of the whole hot path over one batch of synthetic WiderFace-shaped input
+resident in HBM: match+encode of the batch's ground truth (training side) followed by
+decode + threshold + top-k + NMS of the batch's head outputs (inference side), called
+through the C ABI.  Default workload: batch 32 @ 640x640, A = 102 000 anchors, up to 256
+ground-truth boxes per image, score threshold 0.05 (BASELINE.json configs[2]).
+
+  python bench.py --gpus N --steps K --warmup W
+
+For N > 1 run under `python -m torch.distributed.run --nproc-per-node N`: every rank owns
+its own batch (images are independent; no collective inside the timed loop), so scaling is
+weak and `value` is the sum over ranks.  Rank 0 prints one JSON line.
+"""
+import argparse
+import ctypes
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--size", type=int, default=640)
+    ap.add_argument("--gmax", type=int, default=256)
+    ap.add_argument("--ratios", default="config", choices=["config", "model"])
+    ap.add_argument("--score-thr", type=float, default=0.05)
+    ap.add_argument("--stress", action="store_true", help="256 ground-truth boxes in every image")
+    ap.add_argument("--streams", type=int, default=4, help="batches in flight")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-images", type=int, default=3)
+    ap.add_argument("--profile-only", action="store_true",
+                    help="few steps on one stream, no CPU baseline (for rocprofv3 runs)")
+    return ap.parse_args()
+
+
+def relaunch_under_torchrun(args):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", os.environ.get("MASTER_PORT", "29511"), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+class Workload:
+    """Device-resident inputs and per-stream outputs/contexts for one rank."""
+
+    def __init__(self, args, rank):
+        import numpy as np
+        import torch
+        from face_detection_amd import _lib, synthetic as S
+        from face_detection_amd.runtime import Context, geometry_for
+        self.torch, self.np, self.lib_mod = torch, np, _lib
+        self.lib = _lib.load()
+        self.args = args
+        self.cfg = S.reference_ssd_config(args.size, args.ratios)
+        rng = np.random.default_rng(1000 + rank)
+        self.gt_boxes, self.gt_labels, self.gt_counts = S.make_ground_truth(
+            rng, args.batch, args.size, gmax=args.gmax, stress=args.stress)
+        self.y_pred = S.make_head_outputs(rng, self.cfg, self.gt_boxes, self.gt_counts)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        self.geom = geometry_for(self.cfg, dev.index)
+        self.A = self.geom.num_anchors
+        self.d_boxes = torch.from_numpy(self.gt_boxes).to(dev)
+        self.d_labels = torch.from_numpy(self.gt_labels).to(dev)
+        self.d_counts = torch.from_numpy(self.gt_counts).to(dev)
+        self.d_ypred = torch.from_numpy(self.y_pred).to(dev)
+        B, A = args.batch, self.A
+        self.slots = []
+        for _ in range(max(args.streams, 1)):
+            stream = torch.cuda.Stream(device=dev)
+            self.slots.append({
+                "stream": stream,
+                "ctx": Context(dev.index, stream),
+                "conf": torch.empty((B, A), dtype=torch.float32, device=dev),
+                "locs": torch.empty((B, A, 4), dtype=torch.float32, device=dev),
+                "dets": torch.empty((B, 1000, 6), dtype=torch.float32, device=dev),
+                "keep": torch.empty((B, 1000), dtype=torch.int32, device=dev),
+                "count": torch.empty((B,), dtype=torch.int32, device=dev),
+            })
+        torch.cuda.synchronize()
+
+    @staticmethod
+    def _p(t):
+        return ctypes.c_void_p(t.data_ptr())
+
+    def match(self, slot):
+        a = self.args
+        rc = self.lib.ssdbox_match_encode(
+            slot["ctx"].handle, self.geom.handle, None, self.A, self._p(self.d_boxes),
+            self._p(self.d_labels), self._p(self.d_counts), a.batch, a.gmax, float(a.size), 0.5,
+            self._p(slot["conf"]), self._p(slot["locs"]), None, None)
+        if rc != 0:
+            self.lib_mod.check(rc)
+
+    def detect(self, slot):
+        a = self.args
+        rc = self.lib.ssdbox_decode_nms(
+            slot["ctx"].handle, self.geom.handle, None, self.A, self._p(self.d_ypred), a.batch,
+            a.score_thr, 0.45, 1000, None, self._p(slot["dets"]), self._p(slot["keep"]),
+            self._p(slot["count"]))
+        if rc != 0:
+            self.lib_mod.check(rc)
+
+    def step(self, i):
+        slot = self.slots[i % len(self.slots)]
+        self.match(slot)
+        self.detect(slot)
+
+    def algorithmic_bytes(self):
+        """Per batch: match+encode reads 20 B per GT box and writes 20 B per anchor;
+        decode+NMS reads the 24 B head row of every anchor and writes 24 B per kept box
+        plus a 4 B count per image."""
+        B, A = self.args.batch, self.A
+        n_keep = int(self.slots[0]["count"].sum().item())
+        match_bytes = 20 * int(self.gt_counts.sum()) + 20 * A * B
+        detect_bytes = 24 * A * B + 24 * n_keep + 4 * B
+        return match_bytes, detect_bytes, n_keep
+
+
+def timed_loop(torch, dist, world, fn, steps, warmup):
+    for i in range(warmup):
+        fn(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        fn(i)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def stage_times(wl, steps):
+    """Average device time per launch of every kernel stage, from HIP events recorded on the
+    stream the kernels run on (one stream, so the numbers are not overlapped)."""
+    slot = wl.slots[0]
+    ctx = slot["ctx"]
+    for _ in range(5):
+        wl.match(slot)
+        wl.detect(slot)
+    ctx.synchronize()
+    ctx.set_timing(True)
+    for _ in range(steps):
+        wl.match(slot)
+        wl.detect(slot)
+    t = ctx.collect_timing()
+    ctx.set_timing(False)
+    return {k: (ms / n * 1e3) for k, (ms, n) in t.items() if n}       # microseconds
+
+
+def cpu_baseline(wl, n_images):
+    """The numpy restatement of the reference's TF-eager algorithm (materialised (A,G) IoU,
+    O(K^3) NMS loop, Python anchor loop), one core, on the first images of this batch."""
+    np = wl.np
+    from oracle import box_oracle as O
+    t0 = time.perf_counter()
+    anchors = O.generate_anchors(wl.cfg)                  # once per dataset on the training side
+    t_anchor = time.perf_counter() - t0
+    n = min(n_images, wl.args.batch)
+    t_match = t_det = 0.0
+    for b in range(n):
+        g = int(wl.gt_counts[b])
+        t0 = time.perf_counter()
+        O.compute_target(anchors, wl.gt_boxes[b, :g], wl.gt_labels[b, :g], float(wl.args.size))
+        t_match += time.perf_counter() - t0
+        t0 = time.perf_counter()
+        O.generate_anchors(wl.cfg)                        # inference.py:44 regenerates per image
+        O.postprocess(wl.y_pred[b], anchors, wl.args.score_thr, 1.0, 1.0, 0.45, 1000)
+        t_det += time.perf_counter() - t0
+    per_image = (t_match + t_det) / n
+    return {
+        "value": 1.0 / per_image, "unit": "images/sec", "cores": 1, "kind": "port",
+        "sample": "%d images of this batch (G=%s): numpy literal oracle, match+encode %.3f s/img, "
+                  "anchors+decode+NMS %.3f s/img, one-off anchor generation %.2f s"
+                  % (n, [int(x) for x in wl.gt_counts[:n]], t_match / n, t_det / n, t_anchor),
+        "match_encode_images_per_s": n / t_match, "decode_nms_images_per_s": n / t_det,
+    }
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(relaunch_under_torchrun(args))
+
+    import torch
+    import torch.distributed as dist
+    from face_detection_amd import dist as fdist
+    rank, world, _ = fdist.init_from_env()
+    if args.gpus != world and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    if args.profile_only:
+        args.streams = 1
+    wl = Workload(args, rank)
+
+    if args.profile_only:
+        for i in range(args.warmup + args.steps):
+            wl.step(i)
+        torch.cuda.synchronize()
+        return
+
+    elapsed = timed_loop(torch, dist, world, wl.step, args.steps, args.warmup)
+    images = args.batch * args.steps * world
+    value = images / elapsed
+
+    # the two halves on their own (same protocol), for the per-half figures of the metric
+    nslots = len(wl.slots)
+    t_match = timed_loop(torch, dist, world, lambda i: wl.match(wl.slots[i % nslots]), args.steps, 5)
+    t_det = timed_loop(torch, dist, world, lambda i: wl.detect(wl.slots[i % nslots]), args.steps, 5)
+
+    if rank == 0:
+        stages = stage_times(wl, min(args.steps, 100))
+        match_bytes, detect_bytes, n_keep = wl.algorithmic_bytes()
+        per_kernel = {}
+        if "match" in stages:
+            per_kernel["match"] = match_bytes / (stages["match"] * 1e-6) / 1e9
+        if "select" in stages:
+            per_kernel["select"] = detect_bytes / (stages["select"] * 1e-6) / 1e9
+        dominant = max(("match", "select"), key=lambda k: stages.get(k, 0.0))
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dominant)
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "images/sec (match+encode; decode+NMS) b=32 @640^2, % HBM roofline, 1-8 GPU",
+            "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": "SSD+FPN box pipeline, match+encode then decode+NMS per batch, "
+                            "batch %d @%dx%d, A=%d, <=%d GT/image%s, score_thr %.2f, nms 0.45, "
+                            "limit 1000" % (args.batch, args.size, args.size, wl.A, args.gmax,
+                                            " (all 256)" if args.stress else "", args.score_thr),
+                "batch_per_gpu": args.batch, "anchors": wl.A, "gt_total": int(wl.gt_counts.sum()),
+                "kept_total": n_keep, "batches_in_flight": nslots, "parallelism": "image-sharded x%d" % world,
+            },
+            "match_encode_images_per_s": args.batch * args.steps * world / t_match,
+            "decode_nms_images_per_s": args.batch * args.steps * world / t_det,
+            "kernel_us": {k: round(v, 2) for k, v in stages.items()},
+            "roofline": {
+                "bound": "hbm", "kernel": dominant + "_kernel",
+                "achieved": per_kernel[dominant], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": per_kernel[dominant] / HBM_PEAK_GBS, "traffic": traffic,
+                "algorithmic_bytes_per_launch": match_bytes if dominant == "match" else detect_bytes,
+            },
+            "roofline_kernels": {k: {"achieved_GBs": v, "frac": v / HBM_PEAK_GBS} for k, v in per_kernel.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(wl, args.cpu_images)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

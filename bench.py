@@ -42,6 +42,8 @@ def parse_args():
     ap.add_argument("--streams", type=int, default=4, help="batches in flight")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=3)
+    ap.add_argument("--anchors", default="geometry", choices=["geometry", "array"],
+                    help="anchors generated on the fly (default) or read from a materialised array")
     ap.add_argument("--profile-only", action="store_true",
                     help="few steps on one stream, no CPU baseline (for rocprofv3 runs)")
     return ap.parse_args()
@@ -73,6 +75,11 @@ class Workload:
         dev = torch.device("cuda", torch.cuda.current_device())
         self.geom = geometry_for(self.cfg, dev.index)
         self.A = self.geom.num_anchors
+        self.g_handle, self.a_ptr = self.geom.handle, None
+        if args.anchors == "array":
+            from face_detection_amd.runtime import AnchorGrid
+            self.d_anchors = AnchorGrid(self.cfg, dev.index).tensor()
+            self.g_handle, self.a_ptr = None, ctypes.c_void_p(self.d_anchors.data_ptr())
         self.d_boxes = torch.from_numpy(self.gt_boxes).to(dev)
         self.d_labels = torch.from_numpy(self.gt_labels).to(dev)
         self.d_counts = torch.from_numpy(self.gt_counts).to(dev)
@@ -99,7 +106,7 @@ class Workload:
     def match(self, slot):
         a = self.args
         rc = self.lib.ssdbox_match_encode(
-            slot["ctx"].handle, self.geom.handle, None, self.A, self._p(self.d_boxes),
+            slot["ctx"].handle, self.g_handle, self.a_ptr, self.A, self._p(self.d_boxes),
             self._p(self.d_labels), self._p(self.d_counts), a.batch, a.gmax, float(a.size), 0.5,
             self._p(slot["conf"]), self._p(slot["locs"]), None, None)
         if rc != 0:
@@ -108,7 +115,7 @@ class Workload:
     def detect(self, slot):
         a = self.args
         rc = self.lib.ssdbox_decode_nms(
-            slot["ctx"].handle, self.geom.handle, None, self.A, self._p(self.d_ypred), a.batch,
+            slot["ctx"].handle, self.g_handle, self.a_ptr, self.A, self._p(self.d_ypred), a.batch,
             a.score_thr, 0.45, 1000, None, self._p(slot["dets"]), self._p(slot["keep"]),
             self._p(slot["count"]))
         if rc != 0:

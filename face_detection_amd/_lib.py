@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libssdbox.so")
+# SSDBOX_LIB selects another build of the same library (kernel experiments); never a fallback.
+LIB_PATH = os.environ.get("SSDBOX_LIB") or os.path.join(_HERE, "libssdbox.so")
 
 OK = 0
 ERR_INVALID = -1

@@ -246,16 +246,37 @@ extern "C" int ssdbox_geom_create(int device, int img_width, int img_height, int
             L.wmax = fmaxf(L.wmax, L.bw[k]);
             L.hmax = fmaxf(L.hmax, L.bh[k]);
         }
+        // Match-kernel tiling.  A workgroup's ground-truth list grows with the share of the
+        // image its anchors can touch; where that share is large (coarse maps, big boxes) the
+        // tile shrinks from 32 rows (four anchors per thread) to 8 rows (one per thread).
+        {
+            const float fx = fminf(1.0f, (float)kTileCols / (float)(nb > 0 ? nb : 1) / (float)(L.fm_w > 0 ? L.fm_w : 1) + L.wmax);
+            const float fy = fminf(1.0f, (float)kTileRows / (float)(L.fm_h > 0 ? L.fm_h : 1) + L.hmax);
+            L.coarse = (fx * fy > 0.10f) ? 1 : 0;
+        }
+        L.tile_rows = L.coarse ? kCoarseTileRows : kTileRows;
         L.tiles_x = (L.row_anchors + kTileCols - 1) / kTileCols;
-        L.tiles_y = (L.fm_h + kTileRows - 1) / kTileRows;
-        L.tile_base = tiles;
-        tiles += L.tiles_x * L.tiles_y;
+        L.tiles_y = (L.fm_h + L.tile_rows - 1) / L.tile_rows;
+        // multiply-high division constants; each is used for n below the bound checked here
+        auto magic = [](long long d) { return (unsigned)(((1ull << 32) + (unsigned long long)d - 1) / (unsigned long long)d); };
+        L.nbox_magic = nb > 1 ? magic(nb) : 0u;
+        L.rowanc_magic = L.row_anchors > 1 ? magic(L.row_anchors) : 0u;
+        L.tilesx_magic = L.tiles_x > 1 ? magic(L.tiles_x) : 0u;
+        SSD_REQUIRE((long long)L.fm_w * L.fm_h * nb * (long long)(L.row_anchors > 0 ? L.row_anchors : 1) < (1ll << 32) &&
+                        (long long)L.tiles_x * L.tiles_y * (long long)(L.tiles_x > 0 ? L.tiles_x : 1) < (1ll << 32),
+                    "ssdbox_geom_create: layer %d is too large for the index arithmetic", m);
         L.cx_off = (int)cx.size();
         L.cy_off = (int)cy.size();
         for (int j = 0; j < L.fm_w; ++j)        // anchor_utils.py:32
             cx.push_back(fminf(fmaxf((float)((j + offsets) / L.fm_w), 0.0f), 1.0f));
         for (int i = 0; i < L.fm_h; ++i)        // anchor_utils.py:33
             cy.push_back(fminf(fmaxf((float)((i + offsets) / L.fm_h), 0.0f), 1.0f));
+    }
+    // Tiles are numbered from the last (coarsest) layer to the first: workgroups start in
+    // index order, and the coarse tiles carry the longest ground-truth lists.
+    for (int m = n_layers - 1; m >= 0; --m) {
+        g.layer[m].tile_base = tiles;
+        tiles += g.layer[m].tiles_x * g.layer[m].tiles_y;
     }
     g.num_anchors = (int)total;
     g.n_tiles = tiles;

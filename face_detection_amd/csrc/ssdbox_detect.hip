@@ -3,83 +3,107 @@
 // around utils/box_utils.py:126-147 and :184-222).
 //
 // Four launches per batch, none of them per image:
-//   1. score_select_kernel  streams the (B,A,6) head output once, keeps score > threshold
-//      and appends a 64-bit rank key (score order bits, ~anchor index) per survivor to a
-//      per-image candidate list (one atomic per 1024 anchors).
-//   2. topk_sort_kernel     one workgroup per image: radix-select the `limit` largest keys
-//      when there are more than 2048 candidates, bitonic-sort them in LDS (the key order is
-//      "score descending, lower index first", tf.argsort/top_k's order), then decode only
-//      those boxes -- threshold and top-k depend on scores alone.
-//   3. nms_mask_kernel      lower-triangular K x K suppression bits, 64 x 64 per wave,
-//      spread over the chip; bit (j, i) says box i (ranked earlier) suppresses box j, i.e.
-//      !(IoU <= threshold).
-//   4. nms_scan_kernel      one workgroup per image, one thread per ranked box: bands of 64
+//   1. select_*_kernel   streams the (B,A,6) head output once with 16-byte loads, keeps
+//      score > threshold and writes a 64-bit rank key (score order bits, ~anchor index) per
+//      survivor into the wave's own 256-slot segment of the candidate buffer, plus the
+//      segment's count.  No atomics, no barriers: a wave never waits on another.
+//   2. topk_sort_kernel  one workgroup per image: gathers the segments, cuts the candidates
+//      down to the `limit` largest keys with a histogram select (linear score bins first,
+//      key bit fields after), sorts them one key per thread (shuffles inside a wave, LDS
+//      between waves) and decodes only those boxes -- threshold and top-k depend on the
+//      scores alone.  Key order is "score descending, lower index first", which is
+//      tf.argsort(direction='DESCENDING') / top_k's order.
+//   3. nms_mask_kernel   lower-triangular K x K suppression bits, one wave per 64 x 64 tile:
+//      the later box j is wave-uniform, lanes hold 64 earlier boxes i, and a ballot of
+//      !(IoU <= threshold) is the whole 64-bit word (j, word of i).
+//   4. nms_scan_kernel   one workgroup per image, one thread per ranked box: bands of 64
 //      boxes are resolved in order, inside a band by rounds of ballots; kept boxes are
 //      compacted in rank order into the detection rows.
+#include <string.h>
+
 #include "ssdbox_internal.h"
 
 namespace {
 
+typedef unsigned long long u64;
+
+constexpr int kSeg = 256;                  // candidate slots per segment = anchors per wave
 constexpr int kSelBlock = 256;
-constexpr int kSelPerThread = 4;
-constexpr int kSelChunk = kSelBlock * kSelPerThread;
 constexpr int kLimit = SSDBOX_MAX_NMS_LIMIT;
 constexpr int kWords = kLimit / 64;
-constexpr int kSortCap = 2048;
+constexpr int kCap = 4096;                 // keys the top-k kernel stages in LDS
+constexpr int kBucketMax = 256;            // bucket size resolved by direct ranking
+constexpr int kBins = 2048;
 constexpr int kTopkBlock = 1024;
 constexpr float kNmsMaxSize = 512.0f;      // compute_iou's default inside compute_nms (:205)
 
 // ------------------------------------------------------------------------------ select
-__global__ __launch_bounds__(kSelBlock) void score_select_kernel(
-    const float *__restrict__ scores, long long img_stride, int elem_stride, int elem_off, int n,
-    float thr, int use_thr, unsigned long long *__restrict__ cand, long long cand_stride,
-    int *__restrict__ cand_count)
+// Head rows are 24 bytes [bg, face, tx, ty, tw, th]; read as a float4 stream, the face score
+// of anchor 2q sits in .y of float4 3q and that of anchor 2q+1 in .w of float4 3q+1.  A wave
+// owns 384 consecutive float4 (256 anchors): six fully coalesced 1-KiB loads.
+__global__ __launch_bounds__(kSelBlock) void select_rows6_kernel(const float4 *__restrict__ y, int n,
+                                                                 float thr, u64 *__restrict__ cand,
+                                                                 int *__restrict__ seg_count, int nseg)
 {
-    __shared__ int s_cnt[(kSelBlock / 64) * kSelPerThread];
-    __shared__ int s_base;
-    const int t = threadIdx.x;
-    const int lane = t & 63;
-    const int wave = t >> 6;
+    const int lane = threadIdx.x & 63;
+    const int seg = blockIdx.x * (kSelBlock / 64) + (threadIdx.x >> 6);
+    if (seg >= nseg) return;
+    const int img = blockIdx.y;
+    const unsigned nf = (unsigned)n / 2u * 3u;
+    const float4 *src = y + (long long)img * nf;
+    const unsigned f0 = (unsigned)seg * 384u + (unsigned)lane;
+    float4 v[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const unsigned f = f0 + 64u * k;
+        v[k] = (f < nf) ? src[f] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    u64 *out = cand + ((long long)img * nseg + seg) * kSeg;
+    const u64 lt = (1ull << lane) - 1ull;
+    int off = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const unsigned f = f0 + 64u * k;
+        const unsigned q = __umulhi(f, 0xAAAAAAABu) >> 1;      // f / 3
+        const unsigned r = f - 3u * q;
+        const float score = (r == 0u) ? v[k].y : v[k].w;
+        const bool pass = (f < nf) && (r != 2u) && (score > thr);   // strict >, NaN fails
+        const u64 bal = __ballot(pass);
+        if (pass) out[off + __popcll(bal & lt)] = rank_key(score, 2u * q + r);
+        off += __popcll(bal);
+    }
+    if (lane == 0) seg_count[(long long)img * nseg + seg] = off;
+}
+
+// Any score layout (element stride / offset), optional threshold: used for caller-supplied
+// score arrays and for head outputs whose rows are not 16-byte aligned (odd anchor count).
+__global__ __launch_bounds__(kSelBlock) void select_strided_kernel(
+    const float *__restrict__ scores, long long img_stride, int elem_stride, int elem_off, int n,
+    float thr, int use_thr, u64 *__restrict__ cand, int *__restrict__ seg_count, int nseg)
+{
+    const int lane = threadIdx.x & 63;
+    const int seg = blockIdx.x * (kSelBlock / 64) + (threadIdx.x >> 6);
+    if (seg >= nseg) return;
     const int img = blockIdx.y;
     const float *sc = scores + (long long)img * img_stride;
-    const int base = blockIdx.x * kSelChunk;
-
-    float s[kSelPerThread];
-    unsigned long long bal[kSelPerThread];
+    float s[4];
 #pragma unroll
-    for (int q = 0; q < kSelPerThread; ++q) {
-        const int i = base + q * kSelBlock + t;
-        s[q] = (i < n) ? sc[(long long)i * elem_stride + elem_off] : 0.0f;
+    for (int k = 0; k < 4; ++k) {
+        const int i = seg * kSeg + k * 64 + lane;
+        s[k] = (i < n) ? sc[(long long)i * elem_stride + elem_off] : 0.0f;
     }
+    u64 *out = cand + ((long long)img * nseg + seg) * kSeg;
+    const u64 lt = (1ull << lane) - 1ull;
+    int off = 0;
 #pragma unroll
-    for (int q = 0; q < kSelPerThread; ++q) {
-        const int i = base + q * kSelBlock + t;
-        const bool pass = (i < n) && (use_thr ? (s[q] > thr) : true);   // strict >, NaN fails
-        bal[q] = __ballot(pass);
-        if (lane == 0) s_cnt[wave * kSelPerThread + q] = __popcll(bal[q]);
+    for (int k = 0; k < 4; ++k) {
+        const int i = seg * kSeg + k * 64 + lane;
+        const bool pass = (i < n) && (use_thr ? (s[k] > thr) : true);
+        const u64 bal = __ballot(pass);
+        if (pass) out[off + __popcll(bal & lt)] = rank_key(s[k], (uint32_t)i);
+        off += __popcll(bal);
     }
-    __syncthreads();
-    int total = 0;
-    int before[kSelPerThread] = {0, 0, 0, 0};
-#pragma unroll
-    for (int e = 0; e < (kSelBlock / 64) * kSelPerThread; ++e) {
-        const int c = s_cnt[e];
-#pragma unroll
-        for (int q = 0; q < kSelPerThread; ++q)
-            if (e < wave * kSelPerThread + q) before[q] += c;
-        total += c;
-    }
-    if (t == 0) s_base = total ? atomicAdd(&cand_count[img], total) : 0;
-    __syncthreads();
-    unsigned long long *out = cand + (long long)img * cand_stride + s_base;
-    const unsigned long long lt = (1ull << lane) - 1ull;
-#pragma unroll
-    for (int q = 0; q < kSelPerThread; ++q) {
-        if ((bal[q] >> lane) & 1ull) {
-            const int i = base + q * kSelBlock + t;
-            out[before[q] + __popcll(bal[q] & lt)] = rank_key(s[q], (uint32_t)i);
-        }
-    }
+    if (lane == 0) seg_count[(long long)img * nseg + seg] = off;
 }
 
 // ------------------------------------------------------------------------- top-k + sort
@@ -94,134 +118,324 @@ struct BoxSource {
     const float *scores;          // (n), mode 2
 };
 
-__global__ __launch_bounds__(kTopkBlock) void topk_sort_kernel(
-    const unsigned long long *__restrict__ cand, long long cand_stride, int *__restrict__ cand_count,
-    int n_per_image, int limit, BoxSource src, float4 *__restrict__ sboxes,
-    float *__restrict__ sscores, int *__restrict__ sidx, int *__restrict__ keff)
+struct TopkArgs {
+    const u64 *cand;              // (batch, nseg * kSeg)
+    const int *seg_count;         // (batch, nseg)
+    int nseg;
+    int n_per_image;
+    int limit;
+    int has_range;                // scores are expected in [lo, lo + 2047 / scale]
+    float lo, scale;
+    BoxSource src;
+    GeomDev geom;                 // by value (mode 0): layer constants come with the arguments
+    float4 *sboxes;
+    float *sscores;
+    int *sidx;
+    int *keff;
+};
+
+// Monotone non-decreasing map from rank key to one of kBins linear score bins.
+SSD_DEV int linear_bin(u64 key, float lo, float scale)
 {
-    __shared__ unsigned long long s_keys[kSortCap];
-    __shared__ unsigned int s_hist[2048];
+    const uint32_t u = (uint32_t)(key >> 32);
+    if (u == 0u) return 0;                                        // NaN scores rank last
+    const uint32_t b = (u & 0x80000000u) ? (u ^ 0x80000000u) : ~u;  // undo score_key
+    const float x = (u2f(b) - lo) * scale;
+    return (int)fminf(fmaxf(x, 0.0f), (float)(kBins - 1));
+}
+
+// Current bucket of the select: keys whose linear bin (if used) and leading key bits match.
+struct Bucket {
+    int use_lin;      // 1 once the linear pass has fixed a bin
+    int lin;
+    u64 pmask, prefix;
+};
+
+SSD_DEV bool in_bucket(const Bucket &b, u64 key, float lo, float scale)
+{
+    if (b.use_lin && linear_bin(key, lo, scale) != b.lin) return false;
+    return (key & b.pmask) == b.prefix;
+}
+
+SSD_DEV bool above_bucket(const Bucket &b, u64 key, float lo, float scale)
+{
+    if (b.use_lin) {
+        const int l = linear_bin(key, lo, scale);
+        if (l != b.lin) return l > b.lin;
+    }
+    return (key & b.pmask) > b.prefix;
+}
+
+// Value of `x` in lane (lane ^ J), J a power of two below 64: quad permutes for 1 and 2, a
+// swizzle (xor inside each half wave, no address register) for 4..16, a permute across the
+// halves for 32.
+template <int J>
+SSD_DEV unsigned int xor_lane(unsigned int x)
+{
+    if constexpr (J == 1) {
+        return (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xf, 0xf, true);   // [1,0,3,2]
+    } else if constexpr (J == 2) {
+        return (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xf, 0xf, true);   // [2,3,0,1]
+    } else if constexpr (J < 32) {
+        return (unsigned int)__builtin_amdgcn_ds_swizzle((int)x, (J << 10) | 0x1F);
+    } else {
+        return (unsigned int)__shfl_xor((int)x, 32);
+    }
+}
+
+// Bitonic network over kTopkBlock keys, one per thread, descending: compare-exchange
+// distance J inside blocks of K keys, unrolled over the whole network.  Stages wider than
+// the P keys actually present are skipped.  Distances below 64 stay inside a wave;
+// larger ones go through LDS, alternating two buffers so that one barrier per step is enough.
+template <int K, int J>
+struct SortStep {
+    static SSD_DEV void run(u64 &key, int t, u64 (*xchg)[kTopkBlock], int &phase, int P)
+    {
+        if (K <= P) {
+            u64 other;
+            if constexpr (J < 64) {
+                const unsigned int olo = xor_lane<J>((unsigned int)key);
+                const unsigned int ohi = xor_lane<J>((unsigned int)(key >> 32));
+                other = ((u64)ohi << 32) | olo;
+            } else {
+                u64 *buf = xchg[phase & 1];
+                ++phase;
+                buf[t] = key;
+                __syncthreads();
+                other = buf[t ^ J];
+            }
+            const bool take_max = (((t & J) == 0) == ((t & K) == 0));
+            const bool other_gt = other > key;
+            key = (other_gt == take_max) ? other : key;
+        }
+        if constexpr (J > 1) {
+            SortStep<K, J / 2>::run(key, t, xchg, phase, P);
+        } else if constexpr (K < kTopkBlock) {
+            SortStep<K * 2, K>::run(key, t, xchg, phase, P);
+        }
+    }
+};
+
+__global__ __launch_bounds__(kTopkBlock) void topk_sort_kernel(const TopkArgs p)
+{
+    __shared__ u64 s_keys[kCap];
+    __shared__ unsigned int s_hist[kBins];
+    __shared__ u64 s_xchg[2][kTopkBlock];
+    __shared__ u64 s_bucket[kBucketMax];
     __shared__ unsigned int s_wtot[kTopkBlock / 64];
     __shared__ unsigned int s_sel[3];
-    __shared__ int s_count;
+    __shared__ int s_count, s_count2;
 
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = t >> 6;
     const int img = blockIdx.x;
-    const unsigned long long *c = cand + (long long)img * cand_stride;
-    const int n = cand_count[img];
-    __syncthreads();
+    const int nseg = p.nseg;
+    const u64 *cand = p.cand + (long long)img * nseg * kSeg;
+    const int *segc = p.seg_count + (long long)img * nseg;
+    const float lo = p.lo, scale = p.scale;
+
+    // ---- total number of candidates
+    unsigned int mine = 0;
+    for (int s = t; s < nseg; s += kTopkBlock) mine += (unsigned int)segc[s];
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+    if (lane == 0) s_wtot[wave] = mine;
     if (t == 0) {
-        cand_count[img] = 0;       // the list is consumed: leave the counter ready for the next call
-        keff[img] = min(n, limit);
+        s_count = 0;
+        s_count2 = 0;
     }
-    if (n == 0) return;
-    const int K = min(n, limit);
-
-    int m;                         // keys staged in s_keys
-    if (n <= kSortCap) {
-        for (int i = t; i < n; i += kTopkBlock) s_keys[i] = c[i];
-        m = n;
-    } else {
-        // MSB-first radix select on the unique 64-bit keys: narrow to the bucket holding the
-        // K-th largest until everything at or above that bucket fits the sort buffer.
-        unsigned long long pmask = 0ull, prefix = 0ull;
-        int k_rem = K, n_above = 0;
-        for (int pass = 0; pass < 6; ++pass) {
-            const int shift = (pass < 5) ? 53 - 11 * pass : 0;
-            const unsigned int dmask = (pass < 5) ? 0x7FFu : 0x1FFu;
-            s_hist[t] = 0u;
-            s_hist[t + kTopkBlock] = 0u;
-            __syncthreads();
-            for (int i = t; i < n; i += kTopkBlock) {
-                const unsigned long long key = c[i];
-                if ((key & pmask) == prefix) atomicAdd(&s_hist[(unsigned int)(key >> shift) & dmask], 1u);
-            }
-            __syncthreads();
-            const unsigned int h0 = s_hist[2 * t], h1 = s_hist[2 * t + 1];
-            const unsigned int pair = h0 + h1;
-            unsigned int incl = pair;             // suffix sum over this wave's higher lanes
-            for (int o = 1; o < 64; o <<= 1) {
-                const unsigned int v = __shfl_down(incl, o);
-                if (lane + o < 64) incl += v;
-            }
-            if (lane == 0) s_wtot[wave] = incl;
-            __syncthreads();
-            unsigned int above1 = incl - pair;    // keys in bins above 2t+1
-            for (int w = wave + 1; w < kTopkBlock / 64; ++w) above1 += s_wtot[w];
-            const unsigned int above0 = above1 + h1;
-            if ((int)above1 < k_rem && (int)(above1 + h1) >= k_rem) {
-                s_sel[0] = 2 * t + 1;
-                s_sel[1] = above1;
-                s_sel[2] = h1;
-            }
-            if ((int)above0 < k_rem && (int)(above0 + h0) >= k_rem) {
-                s_sel[0] = 2 * t;
-                s_sel[1] = above0;
-                s_sel[2] = h0;
-            }
-            __syncthreads();
-            const unsigned int digit = s_sel[0];
-            const int bucket = (int)s_sel[2];
-            n_above += (int)s_sel[1];
-            k_rem -= (int)s_sel[1];
-            prefix |= (unsigned long long)digit << shift;
-            pmask |= (unsigned long long)dmask << shift;
-            if (n_above + bucket <= kSortCap) break;
-        }
-        if (t == 0) s_count = 0;
-        __syncthreads();
-        for (int i = t; i < n; i += kTopkBlock) {
-            const unsigned long long key = c[i];
-            if ((key & pmask) >= prefix) s_keys[atomicAdd(&s_count, 1)] = key;
-        }
-        __syncthreads();
-        m = s_count;
-    }
-
-    int P = 2;
-    while (P < m) P <<= 1;
-    for (int i = m + t; i < P; i += kTopkBlock) s_keys[i] = 0ull;    // below every real key
     __syncthreads();
-    // bitonic sort, descending
-    for (int k = 2; k <= P; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = t; i < P; i += kTopkBlock) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const unsigned long long a = s_keys[i], b = s_keys[ixj];
-                    const bool desc = ((i & k) == 0);
-                    if ((a < b) == desc) {
-                        s_keys[i] = b;
-                        s_keys[ixj] = a;
+    int n = 0;
+#pragma unroll
+    for (int w = 0; w < kTopkBlock / 64; ++w) n += (int)s_wtot[w];
+    const int K = min(n, p.limit);
+    if (t == 0) p.keff[img] = K;
+    if (n == 0) return;
+
+    Bucket bk;
+    bk.use_lin = 0;
+    bk.lin = 0;
+    bk.pmask = 0ull;
+    bk.prefix = 0ull;
+    int k_rem = K, n_above = 0, bucket = n;
+    int next_digit = p.has_range ? -1 : 0;      // -1: linear bins, 0..5: key bit fields
+    bool in_lds = false;
+    int m_lds = 0;
+
+    while (true) {
+        if (!in_lds && n_above + bucket <= kCap) {
+            // ---- stage every key at or above the bucket in LDS
+            if (bucket == n) {
+                // everything: waves walk the segments, lanes copy a segment's keys
+                // (counts and the first 64 slots of 16 segments are fetched in one round trip;
+                // slots past a segment's count hold stale keys and are not copied)
+                constexpr int kChunk = 16;
+                for (int s0 = wave; s0 < nseg; s0 += kChunk * (kTopkBlock / 64)) {
+                    int cnt[kChunk];
+                    u64 key[kChunk];
+#pragma unroll
+                    for (int u = 0; u < kChunk; ++u) {
+                        const int s = s0 + u * (kTopkBlock / 64);
+                        cnt[u] = (s < nseg) ? segc[s] : 0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < kChunk; ++u) {
+                        const int s = s0 + u * (kTopkBlock / 64);
+                        key[u] = (s < nseg) ? cand[(long long)s * kSeg + lane] : 0ull;
+                    }
+                    int total = 0;
+#pragma unroll
+                    for (int u = 0; u < kChunk; ++u) total += cnt[u];
+                    if (total == 0) continue;                        // wave-uniform
+                    int base = 0;                                    // one reservation per chunk
+                    if (lane == 0) base = atomicAdd(&s_count, total);
+                    base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+                    for (int u = 0; u < kChunk; ++u) {
+                        const int s = s0 + u * (kTopkBlock / 64);
+                        if (lane < cnt[u]) s_keys[base + lane] = key[u];
+                        for (int i = lane + 64; i < cnt[u]; i += 64)
+                            s_keys[base + i] = cand[(long long)s * kSeg + i];
+                        base += cnt[u];
+                    }
+                }
+            } else {
+                for (int s = t; s < nseg * kSeg; s += kTopkBlock) {
+                    if ((s & (kSeg - 1)) < segc[s >> 8]) {
+                        const u64 key = cand[s];
+                        if (above_bucket(bk, key, lo, scale) || in_bucket(bk, key, lo, scale))
+                            s_keys[atomicAdd(&s_count, 1)] = key;
                     }
                 }
             }
             __syncthreads();
+            m_lds = s_count;           // == n_above + bucket
+            in_lds = true;
         }
+        if (in_lds && (m_lds <= kTopkBlock || bucket <= kBucketMax || bucket == k_rem)) break;
+
+        // ---- one histogram pass over the current bucket
+        const int dg = next_digit++;
+        const int shift = (dg < 5) ? 53 - 11 * dg : 0;
+        const unsigned int dmask = (dg < 5) ? 0x7FFu : 0x1FFu;
+        s_hist[t] = 0u;
+        s_hist[t + kTopkBlock] = 0u;
+        __syncthreads();
+        if (in_lds) {
+            for (int i = t; i < m_lds; i += kTopkBlock) {
+                const u64 key = s_keys[i];
+                if (in_bucket(bk, key, lo, scale))
+                    atomicAdd(&s_hist[dg < 0 ? linear_bin(key, lo, scale)
+                                             : (int)((unsigned int)(key >> shift) & dmask)], 1u);
+            }
+        } else {
+            for (int s = t; s < nseg * kSeg; s += kTopkBlock) {
+                if ((s & (kSeg - 1)) < segc[s >> 8]) {
+                    const u64 key = cand[s];
+                    if (in_bucket(bk, key, lo, scale))
+                        atomicAdd(&s_hist[dg < 0 ? linear_bin(key, lo, scale)
+                                                 : (int)((unsigned int)(key >> shift) & dmask)], 1u);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- the digit where the count from the top crosses k_rem
+        const unsigned int h0 = s_hist[2 * t], h1 = s_hist[2 * t + 1];
+        const unsigned int pair = h0 + h1;
+        unsigned int incl = pair;                  // suffix sum over this wave's higher lanes
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned int v = __shfl_down(incl, o);
+            if (lane + o < 64) incl += v;
+        }
+        if (lane == 0) s_wtot[wave] = incl;
+        __syncthreads();
+        unsigned int above1 = incl - pair;         // keys in digits above 2t+1
+        for (int w = wave + 1; w < kTopkBlock / 64; ++w) above1 += s_wtot[w];
+        const unsigned int above0 = above1 + h1;
+        if ((int)above1 < k_rem && (int)(above1 + h1) >= k_rem) {
+            s_sel[0] = 2 * t + 1;
+            s_sel[1] = above1;
+            s_sel[2] = h1;
+        }
+        if ((int)above0 < k_rem && (int)(above0 + h0) >= k_rem) {
+            s_sel[0] = 2 * t;
+            s_sel[1] = above0;
+            s_sel[2] = h0;
+        }
+        __syncthreads();
+        const unsigned int digit = s_sel[0];
+        n_above += (int)s_sel[1];
+        k_rem -= (int)s_sel[1];
+        bucket = (int)s_sel[2];
+        if (dg < 0) {
+            bk.use_lin = 1;
+            bk.lin = (int)digit;
+        } else {
+            bk.prefix |= (u64)digit << shift;
+            bk.pmask |= (u64)dmask << shift;
+        }
+        // after the last bit field the keys (unique) are fully resolved: bucket == 1 == k_rem
     }
 
-    for (int r = t; r < K; r += kTopkBlock) {
-        const uint32_t idx = 0xFFFFFFFFu - (uint32_t)s_keys[r];
+    // ---- the keys to sort: everything staged, or exactly the K largest
+    u64 key = 0ull;                    // padding ranks below every real key
+    int m_sort;
+    if (m_lds <= kTopkBlock) {
+        m_sort = m_lds;
+        if (t < m_lds) key = s_keys[t];
+    } else {
+        u64 *s_out = s_xchg[0];
+        const bool whole_bucket = (bucket == k_rem);
+        for (int i = t; i < m_lds; i += kTopkBlock) {
+            const u64 kk = s_keys[i];
+            if (above_bucket(bk, kk, lo, scale)) {
+                s_out[atomicAdd(&s_count2, 1)] = kk;
+            } else if (in_bucket(bk, kk, lo, scale)) {
+                if (whole_bucket) s_out[atomicAdd(&s_count2, 1)] = kk;
+                else s_bucket[atomicAdd(&s_count, 1) - m_lds] = kk;    // s_count restarts at m_lds
+            }
+        }
+        __syncthreads();
+        if (!whole_bucket && t < bucket) {
+            const u64 me = s_bucket[t];
+            int rank = 0;
+            for (int i = 0; i < bucket; ++i) rank += (s_bucket[i] > me) ? 1 : 0;
+            if (rank < k_rem) s_out[atomicAdd(&s_count2, 1)] = me;
+        }
+        __syncthreads();
+        m_sort = K;                    // == s_count2
+        if (t < K) key = s_out[t];
+        __syncthreads();               // s_xchg is reused by the sort
+    }
+
+    // ---- bitonic sort, descending, one key per thread
+    int P = 64;
+    while (P < m_sort) P <<= 1;
+    int phase = 0;
+    SortStep<2, 1>::run(key, t, s_xchg, phase, P);
+
+    // ---- rank t < K: decode / gather its box
+    if (t < K) {
+        const uint32_t idx = 0xFFFFFFFFu - (uint32_t)key;
         float4 box;
         float score;
-        if (src.mode == 2) {
-            box = src.boxes[idx];
-            score = src.scores[idx];
+        if (p.src.mode == 2) {
+            box = p.src.boxes[idx];
+            score = p.src.scores[idx];
         } else {
-            const float *row = src.y_pred + ((long long)img * n_per_image + idx) * 6;
+            const float *row = p.src.y_pred + ((long long)img * p.n_per_image + idx) * 6;
             score = row[1];
             const float2 lxy = *reinterpret_cast<const float2 *>(row + 2);
             const float2 lwh = *reinterpret_cast<const float2 *>(row + 4);
-            const float4 anc = (src.mode == 0) ? geom_anchor(src.geom, src.cx_tab, src.cy_tab, (int)idx)
-                                               : src.anchors[idx];
+            const float4 anc = (p.src.mode == 0)
+                                   ? geom_anchor(p.geom, p.src.cx_tab, p.src.cy_tab, (int)idx)
+                                   : p.src.anchors[idx];
             box = decode_one(anc, make_float4(lxy.x, lxy.y, lwh.x, lwh.y), 0.1f, 0.2f);
         }
-        const long long o = (long long)img * kLimit + r;
-        sboxes[o] = box;
-        sscores[o] = score;
-        sidx[o] = (int)idx;
+        const long long o = (long long)img * kLimit + t;
+        p.sboxes[o] = box;
+        p.sscores[o] = score;
+        p.sidx[o] = (int)idx;
     }
 }
 
@@ -232,60 +446,64 @@ SSD_DEV float box_area(float4 b, float max_size)
     return clip0(b.z - b.x, max_size) * clip0(b.w - b.y, max_size);
 }
 
+// mask layout: (image, word of earlier boxes, later box j) -> 64 bits, bit i set when box
+// 64*word + i (ranked before j) suppresses j.
 __global__ __launch_bounds__(64) void nms_mask_kernel(const float4 *__restrict__ sboxes,
                                                       const int *__restrict__ keff, float thr,
-                                                      unsigned long long *__restrict__ mask)
+                                                      u64 *__restrict__ mask)
 {
-    __shared__ float4 s_col[64];
-    __shared__ float s_carea[64];
-    const int cw = blockIdx.x;         // column word: earlier-ranked boxes i
-    const int rb = blockIdx.y;         // row band: boxes j
-    const int img = blockIdx.z;
+    __shared__ float4 s_jbox[64];
+    __shared__ float s_jarea[64];
+    const int img = blockIdx.y;
     const int K = keff[img];
-    if (cw > rb || rb * 64 >= K) return;
+    int rb = 0;                        // band of later boxes; word of earlier boxes cw <= rb
+    while ((rb + 1) * (rb + 2) / 2 <= (int)blockIdx.x) ++rb;
+    const int cw = (int)blockIdx.x - rb * (rb + 1) / 2;
+    if (rb * 64 >= K) return;
     const int lane = threadIdx.x;
     const float4 *boxes = sboxes + (long long)img * kLimit;
-    const int j = rb * 64 + lane;
-    const int ci = cw * 64 + lane;
-    const float4 cb = (ci < K) ? boxes[ci] : make_float4(0.f, 0.f, 0.f, 0.f);
-    s_col[lane] = cb;
-    s_carea[lane] = box_area(cb, kNmsMaxSize);
-    const float4 jb = (j < K) ? boxes[j] : make_float4(0.f, 0.f, 0.f, 0.f);
-    const float jarea = box_area(jb, kNmsMaxSize);
+    const int i = cw * 64 + lane;
+    const float4 ib = boxes[min(i, K - 1)];
+    const float iarea = box_area(ib, kNmsMaxSize);
+    const float4 jl = boxes[min(rb * 64 + lane, K - 1)];
+    s_jbox[lane] = jl;
+    s_jarea[lane] = box_area(jl, kNmsMaxSize);
     __syncthreads();
     const bool zero_suppresses = !(0.0f <= thr);
-    unsigned long long bits = 0ull;
-    if (j < K) {
-        const int qn = (cw == rb) ? lane : 64;     // only boxes ranked before j
-        for (int q = 0; q < qn; ++q) {
-            const float4 ib = s_col[q];
-            const float iw = fminf(ib.z, jb.z) - fmaxf(ib.x, jb.x);
-            const float ih = fminf(ib.w, jb.w) - fmaxf(ib.y, jb.y);
-            bool sup;
-            if (iw > 0.0f && ih > 0.0f) {
-                const float inter = fminf(iw, kNmsMaxSize) * fminf(ih, kNmsMaxSize);
-                const float uni = (s_carea[q] + jarea) - inter;
-                const float iou = inter / uni;
-                sup = !(iou <= thr);
-            } else {
-                // intersection 0: IoU is +0 over a positive union, NaN over a zero one
-                const float uni = s_carea[q] + jarea;
-                sup = (uni > 0.0f) ? zero_suppresses : true;
-            }
-            bits |= (unsigned long long)sup << q;
+    const int jn = min(64, K - rb * 64);
+    u64 word = 0ull;                                   // lane q ends up holding the word of box q
+#pragma unroll
+    for (int q = 0; q < 64; ++q) {
+        // (rows past jn repeat the last box; their words are never stored)
+        const float4 jb = s_jbox[q];                   // broadcast read
+        // compute_iou(boxes_a = earlier box, boxes_b = later box), utils/box_utils.py:35-42
+        const float iw = vmin(ib.z, jb.z) - vmax(ib.x, jb.x);
+        const float ih = vmin(ib.w, jb.w) - vmax(ib.y, jb.y);
+        const float asum = iarea + s_jarea[q];
+        bool sup;
+        if (iw > 0.0f && ih > 0.0f) {
+            const float inter = vmin(iw, kNmsMaxSize) * vmin(ih, kNmsMaxSize);
+            const float iou = inter / (asum - inter);
+            sup = !(iou <= thr);
+        } else {
+            // intersection 0: IoU is +0 over a positive union, NaN over a zero one
+            sup = (asum > 0.0f) ? zero_suppresses : true;
         }
-        mask[((long long)img * kLimit + j) * kWords + cw] = bits;
+        // on the diagonal tile box q is itself lane q: bits at and above it are dropped
+        const u64 w = __ballot(sup && (cw != rb || lane < q));
+        if (lane == q) word = w;
     }
+    if (lane < jn) mask[((long long)img * kWords + cw) * kLimit + rb * 64 + lane] = word;
 }
 
 // ---------------------------------------------------------------------------- NMS scan
 __global__ __launch_bounds__(kLimit) void nms_scan_kernel(
-    const unsigned long long *__restrict__ mask, const float4 *__restrict__ sboxes,
+    const u64 *__restrict__ mask, const float4 *__restrict__ sboxes,
     const float *__restrict__ sscores, const int *__restrict__ sidx, const int *__restrict__ keff,
     int limit, const float *__restrict__ img_wh, float *__restrict__ dets,
     int *__restrict__ keep_idx, int *__restrict__ count)
 {
-    __shared__ unsigned long long s_kept[kWords];
+    __shared__ u64 s_kept[kWords];
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int w_me = t >> 6;
@@ -293,18 +511,10 @@ __global__ __launch_bounds__(kLimit) void nms_scan_kernel(
     const int K = keff[img];
     const int KW = (K + 63) >> 6;
 
-    unsigned long long row[kWords];
-    {
-        const ulonglong2 *rp =
-            reinterpret_cast<const ulonglong2 *>(mask + ((long long)img * kLimit + t) * kWords);
+    u64 row[kWords];               // row[c]: earlier boxes of word c that suppress box t
 #pragma unroll
-        for (int c2 = 0; c2 < kWords / 2; ++c2) {
-            ulonglong2 v = make_ulonglong2(0ull, 0ull);
-            if (t < K && 2 * c2 <= w_me) v = rp[c2];
-            row[2 * c2] = v.x;
-            row[2 * c2 + 1] = (2 * c2 + 1 <= w_me) ? v.y : 0ull;
-        }
-    }
+    for (int c = 0; c < kWords; ++c)
+        row[c] = (t < K && c <= w_me) ? mask[((long long)img * kWords + c) * kLimit + t] : 0ull;
     if (t < kWords) s_kept[t] = 0ull;
     bool removed = (t >= K);
     bool kept_me = false;
@@ -316,14 +526,14 @@ __global__ __launch_bounds__(kLimit) void nms_scan_kernel(
             if (w_me == w) {
                 // Greedy order inside the band: a box with no undecided earlier suppressor is
                 // kept; whatever a newly kept box suppresses is dropped; repeat.
-                const unsigned long long D = row[w];
-                unsigned long long U = __ballot(!removed);
-                unsigned long long kept = 0ull;
+                const u64 D = row[w];
+                u64 U = __ballot(!removed);
+                u64 kept = 0ull;
                 while (U != 0ull) {
                     const bool mine = (U >> lane) & 1ull;
-                    const unsigned long long A = __ballot(mine && (D & U) == 0ull);
+                    const u64 A = __ballot(mine && (D & U) == 0ull);
                     kept |= A;
-                    const unsigned long long S = __ballot(mine && (D & A) != 0ull);
+                    const u64 S = __ballot(mine && (D & A) != 0ull);
                     U &= ~(A | S);
                 }
                 kept_me = (kept >> lane) & 1ull;
@@ -353,34 +563,32 @@ __global__ __launch_bounds__(kLimit) void nms_scan_kernel(
             const float4 b = sboxes[o];
             const float W = img_wh ? img_wh[2 * img] : 1.0f;
             const float H = img_wh ? img_wh[2 * img + 1] : 1.0f;
-            float *d = dets + ((long long)img * limit + pos) * 6;
-            d[0] = 1.0f;
-            d[1] = sscores[o];
-            d[2] = clip0(b.x, 1.0f) * W;
-            d[3] = clip0(b.y, 1.0f) * H;
-            d[4] = clip0(b.z, 1.0f) * W;
-            d[5] = clip0(b.w, 1.0f) * H;
+            float2 *d = reinterpret_cast<float2 *>(dets + ((long long)img * limit + pos) * 6);
+            d[0] = make_float2(1.0f, sscores[o]);
+            d[1] = make_float2(clip0(b.x, 1.0f) * W, clip0(b.y, 1.0f) * H);
+            d[2] = make_float2(clip0(b.z, 1.0f) * W, clip0(b.w, 1.0f) * H);
         }
     }
     if (t >= total && t < limit) {
         keep_idx[(long long)img * limit + t] = -1;
         if (dets != nullptr) {
-            float *d = dets + ((long long)img * limit + t) * 6;
-#pragma unroll
-            for (int e = 0; e < 6; ++e) d[e] = 0.0f;
+            float2 *d = reinterpret_cast<float2 *>(dets + ((long long)img * limit + t) * 6);
+            d[0] = make_float2(0.f, 0.f);
+            d[1] = make_float2(0.f, 0.f);
+            d[2] = make_float2(0.f, 0.f);
         }
     }
     if (t == 0) count[img] = total;
 }
 
 // -------------------------------------------------------------------------------- host
-int ensure_detect_scratch(ssdbox_ctx *ctx, int batch, long long n)
+int ensure_detect_scratch(ssdbox_ctx *ctx, int batch, long long nseg)
 {
-    int rc = ensure_buffer((void **)&ctx->cand, &ctx->cand_cap, (size_t)batch * (size_t)n,
-                           sizeof(unsigned long long), false, ctx->stream);
+    int rc = ensure_buffer((void **)&ctx->cand, &ctx->cand_cap, (size_t)batch * (size_t)nseg * kSeg,
+                           sizeof(u64), false, ctx->stream);
     if (rc != SSDBOX_OK) return rc;
-    rc = ensure_buffer((void **)&ctx->cand_count, &ctx->count_cap, (size_t)batch, sizeof(int), true,
-                       ctx->stream);
+    rc = ensure_buffer((void **)&ctx->cand_count, &ctx->count_cap, (size_t)batch * (size_t)nseg,
+                       sizeof(int), false, ctx->stream);
     if (rc != SSDBOX_OK) return rc;
     if ((size_t)batch > ctx->det_cap) {
         SSD_CHECK_HIP(hipStreamSynchronize(ctx->stream));
@@ -398,49 +606,72 @@ int ensure_detect_scratch(ssdbox_ctx *ctx, int batch, long long n)
         if (e == hipSuccess) e = hipMalloc((void **)&ctx->sscores, cap * kLimit * sizeof(float));
         if (e == hipSuccess) e = hipMalloc((void **)&ctx->sidx, cap * kLimit * sizeof(int));
         if (e == hipSuccess) e = hipMalloc((void **)&ctx->keff, cap * sizeof(int));
-        if (e == hipSuccess)
-            e = hipMalloc((void **)&ctx->mask, cap * kLimit * kWords * sizeof(unsigned long long));
+        if (e == hipSuccess) e = hipMalloc((void **)&ctx->mask, cap * kLimit * kWords * sizeof(u64));
         if (e != hipSuccess) {
             set_error("detection scratch allocation failed: %s", hipGetErrorString(e));
             return SSDBOX_ERR_NOMEM;
         }
         ctx->det_cap = cap;
     }
-    if (ctx->count_dirty) {
-        SSD_CHECK_HIP(hipMemsetAsync(ctx->cand_count, 0, ctx->count_cap * sizeof(int), ctx->stream));
-        ctx->count_dirty = false;
-    }
     return SSDBOX_OK;
 }
 
-int run_detect(ssdbox_ctx *ctx, const float *scores, long long img_stride, int elem_stride,
-               int elem_off, long long n, int batch, float thr, int use_thr, float nms_thr,
-               int limit, const BoxSource &src, const float *d_img_wh, float *d_dets,
-               int32_t *d_keep, int32_t *d_count)
+struct ScoreLayout {
+    const float *scores;
+    long long img_stride;
+    int elem_stride, elem_off;
+    int use_thr;
+    float thr;
+    bool rows6;                    // (batch, n, 6) head rows, 16-byte aligned per image
+};
+
+int run_detect(ssdbox_ctx *ctx, const ScoreLayout &sl, long long n, int batch, float nms_thr,
+               int limit, const BoxSource &src, const GeomDev *host_geom, const float *d_img_wh,
+               float *d_dets, int32_t *d_keep, int32_t *d_count)
 {
-    int rc = ensure_detect_scratch(ctx, batch, n);
+    const int nseg = (int)((n + kSeg - 1) / kSeg);
+    int rc = ensure_detect_scratch(ctx, batch, nseg);
     if (rc != SSDBOX_OK) return rc;
-    ctx->count_dirty = true;
     {
         StageTimer timer(ctx, SSDBOX_STAGE_SELECT);
-        dim3 grid((unsigned)((n + kSelChunk - 1) / kSelChunk), batch);
-        hipLaunchKernelGGL(score_select_kernel, grid, dim3(kSelBlock), 0, ctx->stream, scores,
-                           img_stride, elem_stride, elem_off, (int)n, thr, use_thr, ctx->cand,
-                           (long long)n, ctx->cand_count);
+        dim3 grid((unsigned)((nseg + kSelBlock / 64 - 1) / (kSelBlock / 64)), batch);
+        if (sl.rows6) {
+            hipLaunchKernelGGL(select_rows6_kernel, grid, dim3(kSelBlock), 0, ctx->stream,
+                               reinterpret_cast<const float4 *>(sl.scores), (int)n, sl.thr, ctx->cand,
+                               ctx->cand_count, nseg);
+        } else {
+            hipLaunchKernelGGL(select_strided_kernel, grid, dim3(kSelBlock), 0, ctx->stream,
+                               sl.scores, sl.img_stride, sl.elem_stride, sl.elem_off, (int)n, sl.thr,
+                               sl.use_thr, ctx->cand, ctx->cand_count, nseg);
+        }
     }
     SSD_CHECK_HIP(hipGetLastError());
     {
         StageTimer timer(ctx, SSDBOX_STAGE_TOPK);
-        hipLaunchKernelGGL(topk_sort_kernel, dim3(batch), dim3(kTopkBlock), 0, ctx->stream,
-                           ctx->cand, (long long)n, ctx->cand_count, (int)n, limit, src,
-                           ctx->sboxes, ctx->sscores, ctx->sidx, ctx->keff);
+        TopkArgs a;
+        memset(&a, 0, sizeof(a));
+        if (host_geom != nullptr) a.geom = *host_geom;
+        a.cand = ctx->cand;
+        a.seg_count = ctx->cand_count;
+        a.nseg = nseg;
+        a.n_per_image = (int)n;
+        a.limit = limit;
+        // head scores are softmax outputs: spread the linear bins over (threshold, 1]
+        a.has_range = (sl.use_thr && sl.thr >= 0.0f && sl.thr < 1.0f) ? 1 : 0;
+        a.lo = a.has_range ? sl.thr : 0.0f;
+        a.scale = a.has_range ? (float)(kBins - 1) / (1.0f - sl.thr) : 0.0f;
+        a.src = src;
+        a.sboxes = ctx->sboxes;
+        a.sscores = ctx->sscores;
+        a.sidx = ctx->sidx;
+        a.keff = ctx->keff;
+        hipLaunchKernelGGL(topk_sort_kernel, dim3(batch), dim3(kTopkBlock), 0, ctx->stream, a);
     }
     SSD_CHECK_HIP(hipGetLastError());
-    ctx->count_dirty = false;
     {
         StageTimer timer(ctx, SSDBOX_STAGE_NMS_MASK);
         const int kw = (limit + 63) / 64;
-        hipLaunchKernelGGL(nms_mask_kernel, dim3(kw, kw, batch), dim3(64), 0, ctx->stream,
+        hipLaunchKernelGGL(nms_mask_kernel, dim3(kw * (kw + 1) / 2, batch), dim3(64), 0, ctx->stream,
                            ctx->sboxes, ctx->keff, nms_thr, ctx->mask);
     }
     SSD_CHECK_HIP(hipGetLastError());
@@ -495,9 +726,17 @@ extern "C" int ssdbox_decode_nms(ssdbox_ctx *ctx, const ssdbox_geom *geom, const
     src.y_pred = d_y_pred;
     src.boxes = nullptr;
     src.scores = nullptr;
-    return run_detect(ctx, d_y_pred, (long long)num_anchors * 6, 6, 1, num_anchors, batch,
-                      score_threshold, 1, nms_threshold, limit, src, d_img_wh, d_dets, d_keep_idx,
-                      d_count);
+    ScoreLayout sl;
+    sl.scores = d_y_pred;
+    sl.img_stride = (long long)num_anchors * 6;
+    sl.elem_stride = 6;
+    sl.elem_off = 1;
+    sl.use_thr = 1;
+    sl.thr = score_threshold;
+    sl.rows6 = (num_anchors % 2 == 0) && (reinterpret_cast<uintptr_t>(d_y_pred) % 16 == 0);
+    return run_detect(ctx, sl, num_anchors, batch, nms_threshold, limit, src,
+                      geom ? &geom->host : nullptr, d_img_wh, d_dets,
+                      d_keep_idx, d_count);
 }
 
 extern "C" int ssdbox_compute_nms(ssdbox_ctx *ctx, const float *d_boxes, const float *d_scores,
@@ -529,6 +768,14 @@ extern "C" int ssdbox_compute_nms(ssdbox_ctx *ctx, const float *d_boxes, const f
     src.y_pred = nullptr;
     src.boxes = reinterpret_cast<const float4 *>(d_boxes);
     src.scores = d_scores;
-    return run_detect(ctx, d_scores, 0, 1, 0, n, 1, 0.0f, 0, nms_threshold, k, src, nullptr,
-                      nullptr, d_keep, d_count);
+    ScoreLayout sl;
+    sl.scores = d_scores;
+    sl.img_stride = 0;
+    sl.elem_stride = 1;
+    sl.elem_off = 0;
+    sl.use_thr = 0;
+    sl.thr = 0.0f;
+    sl.rows6 = false;
+    return run_detect(ctx, sl, n, 1, nms_threshold, k, src, nullptr, nullptr, nullptr, d_keep,
+                      d_count);
 }

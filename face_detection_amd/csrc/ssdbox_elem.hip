@@ -108,6 +108,10 @@ __global__ void selftest_kernel(const float *x_log, const float *e_log, const fl
         float ref = v;
         for (int o = 32; o > 0; o >>= 1) ref = fmaxf(ref, __shfl_xor(ref, o));
         if (wave_max_nonneg(v) != ref) atomicOr(fail, 1);
+        const uint32_t u = (pat == 2) ? 0xFFFFFFFFu : (uint32_t)((t * 2654435761u) >> (pat * 3)) + blockIdx.x;
+        uint32_t uref = u;
+        for (int o = 32; o > 0; o >>= 1) uref = min(uref, (uint32_t)__shfl_xor((int)uref, o));
+        if (wave_min_u32(u) != uref) atomicOr(fail, 1);
     }
     if (lane_id() != (t & 63)) atomicOr(fail, 2);
     for (int i = blockIdx.x * blockDim.x + t; i < n; i += gridDim.x * blockDim.x) {

@@ -14,7 +14,9 @@
 // and per-row centre tables (float32, already clipped) live in device memory because they
 // are the only part whose size grows with the image (sum of fm_w + fm_h floats).
 // ---------------------------------------------------------------------------------------
-constexpr int kTileRows = 8;       // match kernel: feature-map rows per workgroup tile
+constexpr int kRowsPerThread = 4;  // match kernel: anchors (rows of one column) per thread
+constexpr int kTileRows = 8 * kRowsPerThread;   // feature-map rows per workgroup tile
+constexpr int kCoarseTileRows = 8;  // rows per tile on coarse maps (one anchor per thread)
 constexpr int kTileCols = 32;      // match kernel: anchor columns (cell * n_box + k) per tile
 constexpr int kBlock = 256;
 
@@ -24,6 +26,12 @@ struct LayerDev {
     int row_anchors;               // fm_w * n_box
     int tiles_x, tiles_y, tile_base;
     int cx_off, cy_off;            // offsets of this layer in the centre tables
+    unsigned nbox_magic;           // ceil(2^32 / n_box), row_anchors, tiles_x: exact n / d by
+    unsigned rowanc_magic;         // one multiply-high for every n these kernels divide
+    unsigned tilesx_magic;
+    int coarse;                    // 1: 8-row tiles, one anchor per thread (long box lists)
+    int tile_rows;                 // feature-map rows per workgroup tile in this layer
+    int pad_;
     float wmax, hmax;              // largest clipped box width / height of the layer
     float bw[SSDBOX_MAX_BOXES_PER_CELL];
     float bh[SSDBOX_MAX_BOXES_PER_CELL];
@@ -137,6 +145,22 @@ int ensure_buffer(void **ptr, size_t *cap, size_t need, size_t elem_size, bool z
 SSD_DEV uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
 SSD_DEV float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
 
+// One v_min_f32 / v_max_f32 each: the same value as fminf / fmaxf for every quiet input (a
+// NaN operand yields the other one), without the canonicalising copies hipcc puts in front
+// of the library calls when an operand comes straight from memory.
+SSD_DEV float vmin(float a, float b)
+{
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+SSD_DEV float vmax(float a, float b)
+{
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // clip_by_value(x, 0, hi) of reference utils/box_utils.py:15 for hi >= 0.
 SSD_DEV float clip0(float x, float hi) { return fminf(fmaxf(x, 0.0f), hi); }
 
@@ -210,20 +234,33 @@ SSD_DEV float ssd_expf(float x)
     return z * u2f((uint32_t)(n + 127) << 23);
 }
 
+// n / d for d >= 1 with magic = ceil(2^32 / d); exact while n * d < 2^32 (checked when the
+// geometry is built).
+SSD_DEV int udiv_magic(int n, int d, unsigned magic)
+{
+    return d == 1 ? n : (int)__umulhi((unsigned)n, magic);
+}
+
 // Anchor a of a geometry: [cx, cy, w, h] (reference utils/anchor_utils.py:28-60 order:
 // layer, row, column, box).
-SSD_DEV float4 geom_anchor(const GeomDev *__restrict__ g, const float *__restrict__ cx_tab,
+SSD_DEV float4 geom_anchor(const GeomDev &g, const float *__restrict__ cx_tab,
                            const float *__restrict__ cy_tab, int a)
 {
     int m = 0;
-    while (m + 1 < g->n_layers && a >= g->layer[m + 1].anchor_base) ++m;
-    const LayerDev &L = g->layer[m];
+    while (m + 1 < g.n_layers && a >= g.layer[m + 1].anchor_base) ++m;
+    const LayerDev &L = g.layer[m];
     int r = a - L.anchor_base;
-    int i = r / L.row_anchors;
+    int i = udiv_magic(r, L.row_anchors, L.rowanc_magic);
     int c = r - i * L.row_anchors;
-    int j = c / L.n_box;
+    int j = udiv_magic(c, L.n_box, L.nbox_magic);
     int k = c - j * L.n_box;
     return make_float4(cx_tab[L.cx_off + j], cy_tab[L.cy_off + i], L.bw[k], L.bh[k]);
+}
+
+SSD_DEV float4 geom_anchor(const GeomDev *__restrict__ g, const float *__restrict__ cx_tab,
+                           const float *__restrict__ cy_tab, int a)
+{
+    return geom_anchor(*g, cx_tab, cy_tab, a);
 }
 
 // encode of reference utils/box_utils.py:101-123 for one anchor [cx,cy,w,h] and one corner
@@ -266,6 +303,21 @@ SSD_DEV float wave_max_nonneg(float v)
     x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false));
     x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false));
     return u2f((uint32_t)__builtin_amdgcn_readlane(x, 63));
+}
+
+// Minimum over the 64 lanes of a wave of an unsigned value (identity 0xFFFFFFFF), returned
+// in every lane.  Same data movement as wave_max_nonneg.
+SSD_DEV uint32_t wave_min_u32(uint32_t v)
+{
+    const int id = (int)0xFFFFFFFFu;
+    int x = (int)v;
+    x = (int)min((uint32_t)x, (uint32_t)__builtin_amdgcn_update_dpp(id, x, 0x111, 0xf, 0xf, false));
+    x = (int)min((uint32_t)x, (uint32_t)__builtin_amdgcn_update_dpp(id, x, 0x112, 0xf, 0xf, false));
+    x = (int)min((uint32_t)x, (uint32_t)__builtin_amdgcn_update_dpp(id, x, 0x114, 0xf, 0xf, false));
+    x = (int)min((uint32_t)x, (uint32_t)__builtin_amdgcn_update_dpp(id, x, 0x118, 0xf, 0xf, false));
+    x = (int)min((uint32_t)x, (uint32_t)__builtin_amdgcn_update_dpp(id, x, 0x142, 0xa, 0xf, false));
+    x = (int)min((uint32_t)x, (uint32_t)__builtin_amdgcn_update_dpp(id, x, 0x143, 0xc, 0xf, false));
+    return (uint32_t)__builtin_amdgcn_readlane(x, 63);
 }
 
 SSD_DEV int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }

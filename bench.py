@@ -41,7 +41,7 @@ def parse_args():
     ap.add_argument("--stress", action="store_true", help="256 ground-truth boxes in every image")
     ap.add_argument("--streams", type=int, default=4, help="batches in flight")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-images", type=int, default=3)
+    ap.add_argument("--cpu-images", type=int, default=24)
     ap.add_argument("--anchors", default="geometry", choices=["geometry", "array"],
                     help="anchors generated on the fly (default) or read from a materialised array")
     ap.add_argument("--profile-only", action="store_true",
@@ -204,6 +204,50 @@ def cpu_baseline(wl, n_images):
     }
 
 
+def pcie_times(wl, reps=5):
+    """Host<->device transfer time of one batch through pinned memory (inputs: head outputs
+    and ground truth; outputs: targets and detections).  Reported next to `value`, which is
+    measured with inputs already resident in HBM."""
+    torch = wl.torch
+    slot = wl.slots[0]
+    h_in = [torch.from_numpy(x).pin_memory() for x in (wl.y_pred, wl.gt_boxes, wl.gt_labels, wl.gt_counts)]
+    d_in = [wl.d_ypred, wl.d_boxes, wl.d_labels, wl.d_counts]
+    d_out = [slot["conf"], slot["locs"], slot["dets"], slot["keep"], slot["count"]]
+    h_out = [torch.empty(t.shape, dtype=t.dtype).pin_memory() for t in d_out]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        for h, d in zip(h_in, d_in):
+            d.copy_(h, non_blocking=True)
+        torch.cuda.synchronize()
+    h2d = (time.perf_counter() - t0) / reps
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        for h, d in zip(h_out, d_out):
+            h.copy_(d, non_blocking=True)
+        torch.cuda.synchronize()
+    d2h = (time.perf_counter() - t0) / reps
+    nbytes_in = sum(h.numel() * h.element_size() for h in h_in)
+    nbytes_out = sum(h.numel() * h.element_size() for h in h_out)
+    return {"h2d_ms": h2d * 1e3, "d2h_ms": d2h * 1e3, "h2d_bytes": nbytes_in, "d2h_bytes": nbytes_out}
+
+
+def single_batch_latency(wl, reps=30):
+    """Wall time of one step on one stream with nothing else in flight."""
+    torch = wl.torch
+    slot = wl.slots[0]
+    for _ in range(3):
+        wl.match(slot)
+        wl.detect(slot)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        wl.match(slot)
+        wl.detect(slot)
+        torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -233,6 +277,21 @@ def main():
     nslots = len(wl.slots)
     t_match = timed_loop(torch, dist, world, lambda i: wl.match(wl.slots[i % nslots]), args.steps, 5)
     t_det = timed_loop(torch, dist, world, lambda i: wl.detect(wl.slots[i % nslots]), args.steps, 5)
+
+    # the optional collective, outside the timed loop: every rank receives all detections
+    allgather_ms = None
+    if world > 1:
+        slot = wl.slots[0]
+        gb = args.batch * world
+        for _ in range(3):
+            fdist.all_gather_detections(slot["dets"], slot["keep"], slot["count"], gb)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            fdist.all_gather_detections(slot["dets"], slot["keep"], slot["count"], gb)
+        torch.cuda.synchronize()
+        allgather_ms = (time.perf_counter() - t0) / 10 * 1e3
 
     if rank == 0:
         stages = stage_times(wl, min(args.steps, 100))
@@ -275,6 +334,14 @@ def main():
             },
             "roofline_kernels": {k: {"achieved_GBs": v, "frac": v / HBM_PEAK_GBS} for k, v in per_kernel.items()},
         }
+        lat = single_batch_latency(wl)
+        out["single_batch_latency_ms"] = lat * 1e3
+        if allgather_ms is not None:
+            out["allgather_detections_ms"] = allgather_ms
+        pcie = pcie_times(wl)
+        step_s = elapsed / args.steps
+        pcie["images_per_s_with_transfers_serial"] = args.batch / (step_s + (pcie["h2d_ms"] + pcie["d2h_ms"]) * 1e-3)
+        out["pcie"] = pcie
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, args.cpu_images)
         print(json.dumps(out))

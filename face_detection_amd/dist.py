@@ -34,7 +34,8 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if use_gpu else "gloo"
+            # SSDBOX_DIST_BACKEND=gloo lets several ranks share one GPU for a rehearsal
+            backend = os.environ.get("SSDBOX_DIST_BACKEND") or ("nccl" if use_gpu else "gloo")
         if backend == "nccl":
             dist.init_process_group(backend, rank=rank, world_size=world,
                                     device_id=torch.device("cuda", torch.cuda.current_device()))
@@ -77,8 +78,12 @@ def all_gather_detections(dets, keep_idx, count, global_batch, group=None):
     per_rank = -(-global_batch // world)
     block = torch.zeros((per_rank, limit * 7 + 1), dtype=torch.int32, device=dets.device)
     block[: hi - lo] = pack_detections(dets, keep_idx, count)
-    gathered = torch.empty((world * per_rank, limit * 7 + 1), dtype=torch.int32, device=dets.device)
+    device = dets.device
+    if device.type == "cuda" and dist.get_backend(group) == "gloo":
+        block = block.cpu()            # gloo gathers host memory; RCCL gathers in place over xGMI
+    gathered = torch.empty((world * per_rank, limit * 7 + 1), dtype=torch.int32, device=block.device)
     dist.all_gather_into_tensor(gathered, block, group=group)
+    gathered = gathered.to(device)
     parts = []
     for r in range(world):
         r_lo, r_hi = shard_range(global_batch, r, world)

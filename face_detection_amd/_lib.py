@@ -16,8 +16,8 @@ ERR_HIP = -2
 ERR_NOMEM = -3
 ERR_UNSUPPORTED = -4
 
-NUM_STAGES = 7
-STAGE_NAMES = ("match", "force", "select", "topk", "nms_mask", "nms_scan", "elementwise")
+NUM_STAGES = 8
+STAGE_NAMES = ("match", "force", "select", "topk", "nms_mask", "nms_scan", "elementwise", "shapes")
 MAX_NMS_LIMIT = 1024
 MAX_GT = 4096
 MAX_LAYERS = 8

@@ -113,7 +113,7 @@ extern "C" int ssdbox_ctx_destroy(ssdbox_ctx *ctx)
         (void)hipEventDestroy(r.stop);
     }
     for (auto &e : ctx->event_pool) (void)hipEventDestroy(e);
-    void *bufs[] = {ctx->gkey, ctx->cand, ctx->cand_count, ctx->sboxes, ctx->sscores,
+    void *bufs[] = {ctx->gkey, ctx->shape_tab, ctx->b0_tab, ctx->work_counter, ctx->cand, ctx->cand_count, ctx->sboxes, ctx->sscores,
                     ctx->sidx, ctx->keff, ctx->mask, ctx->selftest_out};
     for (void *b : bufs)
         if (b != nullptr) (void)hipFree(b);
@@ -195,6 +195,7 @@ extern "C" int ssdbox_geom_create(int device, int img_width, int img_height, int
     memset(&g, 0, sizeof(g));
     g.n_layers = n_layers;
     std::vector<float> cx, cy;
+    std::vector<float4> col;
     long long total = 0;
     int tiles = 0;
     const double *ratios = ratios_flat;
@@ -236,6 +237,13 @@ extern "C" int ssdbox_geom_create(int device, int img_width, int img_height, int
         }
         ratios += ratio_counts[m];
         L.n_box = nb;
+        L.k_off = g.k_total;
+        g.k_total += nb;
+        // one tile of padding per layer: the match kernel reads past the edge unclamped
+        L.col_off = g.col_total;
+        g.col_total += L.fm_w * nb + kTileCols;
+        L.rowk_off = g.rowk_total;
+        g.rowk_total += (L.fm_h + kTileRows) * nb;
         L.anchor_base = (int)total;
         L.row_anchors = L.fm_w * nb;
         total += (long long)L.fm_w * L.fm_h * nb;
@@ -271,6 +279,12 @@ extern "C" int ssdbox_geom_create(int device, int img_width, int img_height, int
             cx.push_back(fminf(fmaxf((float)((j + offsets) / L.fm_w), 0.0f), 1.0f));
         for (int i = 0; i < L.fm_h; ++i)        // anchor_utils.py:33
             cy.push_back(fminf(fmaxf((float)((i + offsets) / L.fm_h), 0.0f), 1.0f));
+        for (int i = 0; i < kTileRows; ++i) cy.push_back(L.fm_h > 0 ? cy.back() : 0.0f);
+        for (int j = 0; j < L.fm_w; ++j)
+            for (int k = 0; k < nb; ++k)
+                col.push_back(make_float4(cx[L.cx_off + j], L.bw[k], L.bh[k], 0.0f));
+        for (int c = 0; c < kTileCols; ++c)
+            col.push_back(L.fm_w > 0 && nb > 0 ? col.back() : make_float4(0.0f, 1.0f, 1.0f, 0.0f));
     }
     // Tiles are numbered from the last (coarsest) layer to the first: workgroups start in
     // index order, and the coarse tiles carry the longest ground-truth lists.
@@ -287,6 +301,7 @@ extern "C" int ssdbox_geom_create(int device, int img_width, int img_height, int
     geom->d_geom = nullptr;
     geom->d_cx = nullptr;
     geom->d_cy = nullptr;
+    geom->d_col = nullptr;
     if (device < 0) {           // host-only handle: layer table and counts, no kernels
         *out = geom;
         return SSDBOX_OK;
@@ -304,6 +319,9 @@ extern "C" int ssdbox_geom_create(int device, int img_width, int img_height, int
     hipError_t e = hipMalloc((void **)&geom->d_geom, sizeof(GeomDev));
     if (e == hipSuccess) e = hipMalloc((void **)&geom->d_cx, ncx * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void **)&geom->d_cy, ncy * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&geom->d_col, (col.size() ? col.size() : 1) * sizeof(float4));
+    if (e == hipSuccess && !col.empty())
+        e = hipMemcpy(geom->d_col, col.data(), col.size() * sizeof(float4), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(geom->d_geom, &g, sizeof(GeomDev), hipMemcpyHostToDevice);
     if (e == hipSuccess && !cx.empty())
         e = hipMemcpy(geom->d_cx, cx.data(), cx.size() * sizeof(float), hipMemcpyHostToDevice);
@@ -329,6 +347,7 @@ extern "C" int ssdbox_geom_destroy(ssdbox_geom *geom)
     if (geom->d_geom) (void)hipFree(geom->d_geom);
     if (geom->d_cx) (void)hipFree(geom->d_cx);
     if (geom->d_cy) (void)hipFree(geom->d_cy);
+    if (geom->d_col) (void)hipFree(geom->d_col);
     delete geom;
     return SSDBOX_OK;
 }

@@ -31,7 +31,9 @@ struct LayerDev {
     unsigned tilesx_magic;
     int coarse;                    // 1: 8-row tiles, one anchor per thread (long box lists)
     int tile_rows;                 // feature-map rows per workgroup tile in this layer
-    int pad_;
+    int k_off;                     // index of the layer's first box shape among all layers' shapes
+    int col_off;                   // the layer's first entry in the anchor-column tables
+    int rowk_off;                  // the layer's first entry in the (row, shape) table
     float wmax, hmax;              // largest clipped box width / height of the layer
     float bw[SSDBOX_MAX_BOXES_PER_CELL];
     float bh[SSDBOX_MAX_BOXES_PER_CELL];
@@ -41,7 +43,9 @@ struct GeomDev {
     int n_layers;
     int num_anchors;
     int n_tiles;
-    int pad_;
+    int k_total;                   // box shapes of all layers together (sum of n_box)
+    int col_total;                 // anchor columns of all layers (sum of fm_w * n_box)
+    int rowk_total;                // (row, shape) pairs of all layers (sum of fm_h * n_box)
     LayerDev layer[SSDBOX_MAX_LAYERS];
 };
 
@@ -49,6 +53,7 @@ struct ssdbox_geom {
     int device;
     GeomDev host;                  // host copy of what d_geom points to
     GeomDev *d_geom;
+    float4 *d_col;                 // per anchor column of every layer: cx, w, h, shape index bits
     float *d_cx;                   // concatenated per-layer column centres
     float *d_cy;                   // concatenated per-layer row centres
 };
@@ -74,6 +79,14 @@ struct ssdbox_ctx {
     unsigned long long *gkey;
     size_t gkey_cap;               // entries
     bool gkey_dirty;
+    // match scratch: log-size offsets of every (image, GT box, box shape) triple
+    float2 *shape_tab;
+    size_t shape_cap;
+    // match scratch: offsets of every anchor column (x) and (row, shape) pair (y) against
+    // box 0 of each image
+    float *b0_tab;
+    size_t b0_cap;
+    int *work_counter;             // match kernel's item tickets; zero between calls
 
     // detection scratch
     unsigned long long *cand;      // (batch, N) candidate keys
@@ -246,8 +259,12 @@ SSD_DEV int udiv_magic(int n, int d, unsigned magic)
 SSD_DEV float4 geom_anchor(const GeomDev &g, const float *__restrict__ cx_tab,
                            const float *__restrict__ cy_tab, int a)
 {
+    // anchor_base grows with the layer, so the layer is a count; every comparison reads a
+    // fixed field (no chain of dependent loads)
     int m = 0;
-    while (m + 1 < g.n_layers && a >= g.layer[m + 1].anchor_base) ++m;
+#pragma unroll
+    for (int l = 1; l < SSDBOX_MAX_LAYERS; ++l)
+        m += (l < g.n_layers && a >= g.layer[l].anchor_base) ? 1 : 0;
     const LayerDev &L = g.layer[m];
     int r = a - L.anchor_base;
     int i = udiv_magic(r, L.row_anchors, L.rowanc_magic);

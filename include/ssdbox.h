@@ -47,7 +47,8 @@ enum {
     SSDBOX_STAGE_NMS_MASK = 4,   /* K x K suppression bit matrix                             */
     SSDBOX_STAGE_NMS_SCAN = 5,   /* greedy scan + detection assembly                         */
     SSDBOX_STAGE_ELEMENTWISE = 6,
-    SSDBOX_NUM_STAGES = 7
+    SSDBOX_STAGE_SHAPES = 7,     /* per (GT box, anchor shape) log-size table before matching */
+    SSDBOX_NUM_STAGES = 8
 };
 
 int ssdbox_version(void);

@@ -448,12 +448,26 @@ SSD_DEV float box_area(float4 b, float max_size)
 
 // mask layout: (image, word of earlier boxes, later box j) -> 64 bits, bit i set when box
 // 64*word + i (ranked before j) suppresses j.
+//
+// One wave per 64 x 64 tile of (earlier, later) pairs.  Few pairs of a tile overlap at all,
+// and a pair that does not overlap has IoU +0: with a threshold >= 0 and boxes of positive
+// area it suppresses nothing.  So the tile is first swept for overlapping pairs only (four
+// min/max and two compares per pair), the overlapping pairs are listed in LDS, and the IoU
+// with its division is taken for 64 listed pairs at a time.  Tiles with a NaN coordinate, a
+// box of zero area, a negative threshold or more listed pairs than the list holds take the
+// plain pair-by-pair loop.
+constexpr int kPairCap = 1536;     // listed pairs per tile on the fast path
+
 __global__ __launch_bounds__(64) void nms_mask_kernel(const float4 *__restrict__ sboxes,
                                                       const int *__restrict__ keff, float thr,
                                                       u64 *__restrict__ mask)
 {
     __shared__ float4 s_jbox[64];
     __shared__ float s_jarea[64];
+    __shared__ float4 s_ibox[64];
+    __shared__ float s_iarea[64];
+    __shared__ unsigned short s_pair[kPairCap];
+    __shared__ u64 s_res[64];
     const int img = blockIdx.y;
     const int K = keff[img];
     int rb = 0;                        // band of later boxes; word of earlier boxes cw <= rb
@@ -466,11 +480,69 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float4 *__restrict__
     const float4 ib = boxes[min(i, K - 1)];
     const float iarea = box_area(ib, kNmsMaxSize);
     const float4 jl = boxes[min(rb * 64 + lane, K - 1)];
+    const float jarea = box_area(jl, kNmsMaxSize);
     s_jbox[lane] = jl;
-    s_jarea[lane] = box_area(jl, kNmsMaxSize);
+    s_jarea[lane] = jarea;
+    s_ibox[lane] = ib;
+    s_iarea[lane] = iarea;
+    s_res[lane] = 0ull;
     __syncthreads();
     const bool zero_suppresses = !(0.0f <= thr);
     const int jn = min(64, K - rb * 64);
+
+    // finite coordinates and positive areas on both sides, threshold >= 0
+    const bool plain = (ib.x - ib.x == 0.0f) && (ib.y - ib.y == 0.0f) && (ib.z - ib.z == 0.0f) &&
+                       (ib.w - ib.w == 0.0f) && (jl.x - jl.x == 0.0f) && (jl.y - jl.y == 0.0f) &&
+                       (jl.z - jl.z == 0.0f) && (jl.w - jl.w == 0.0f) && iarea > 0.0f && jarea > 0.0f;
+    if (!zero_suppresses && __ballot(!plain) == 0ull) {
+        const bool i_ok = i < K;
+        u64 cand = 0ull;                               // lane q: earlier boxes overlapping later box q
+#pragma unroll
+        for (int q = 0; q < 64; ++q) {
+            const float4 jb = s_jbox[q];               // broadcast read
+            const float iw = vmin(ib.z, jb.z) - vmax(ib.x, jb.x);
+            const float ih = vmin(ib.w, jb.w) - vmax(ib.y, jb.y);
+            const u64 w = __ballot(iw > 0.0f && ih > 0.0f);
+            if (lane == q) cand = w;
+        }
+        cand &= __ballot(i_ok);
+        // on the diagonal tile box q is itself lane q: bits at and above it are dropped
+        if (cw == rb) cand &= (1ull << lane) - 1ull;
+        if (lane >= jn) cand = 0ull;
+        const int cnt = __popcll(cand);
+        int incl = cnt;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        if (total <= kPairCap) {
+            int e = incl - cnt;
+            u64 w = cand;
+            while (w != 0ull) {
+                const int pos = __builtin_ctzll(w);
+                w &= w - 1ull;
+                s_pair[e++] = (unsigned short)((lane << 6) | pos);
+            }
+            __syncthreads();
+            for (int d = lane; d < total; d += 64) {
+                const int pr = s_pair[d];
+                const int j = pr >> 6, ii = pr & 63;
+                const float4 a = s_ibox[ii], b = s_jbox[j];
+                // compute_iou(boxes_a = earlier box, boxes_b = later box), utils/box_utils.py:35-42
+                const float iw = vmin(a.z, b.z) - vmax(a.x, b.x);
+                const float ih = vmin(a.w, b.w) - vmax(a.y, b.y);
+                const float asum = s_iarea[ii] + s_jarea[j];
+                const float inter = vmin(iw, kNmsMaxSize) * vmin(ih, kNmsMaxSize);
+                const float iou = inter / (asum - inter);
+                if (!(iou <= thr)) atomicOr(&s_res[j], 1ull << ii);
+            }
+            __syncthreads();
+            if (lane < jn) mask[((long long)img * kWords + cw) * kLimit + rb * 64 + lane] = s_res[lane];
+            return;
+        }
+    }
+
     u64 word = 0ull;                                   // lane q ends up holding the word of box q
 #pragma unroll
     for (int q = 0; q < 64; ++q) {

@@ -14,7 +14,10 @@
 // and per-row centre tables (float32, already clipped) live in device memory because they
 // are the only part whose size grows with the image (sum of fm_w + fm_h floats).
 // ---------------------------------------------------------------------------------------
-constexpr int kRowsPerThread = 4;  // match kernel: anchors (rows of one column) per thread
+#ifndef SSD_EXP_R                  // timing experiment only
+#define SSD_EXP_R 4
+#endif
+constexpr int kRowsPerThread = SSD_EXP_R;  // match kernel: anchors (rows of one column) per thread
 constexpr int kTileRows = 8 * kRowsPerThread;   // feature-map rows per workgroup tile
 constexpr int kCoarseTileRows = 8;  // rows per tile on coarse maps (one anchor per thread)
 constexpr int kTileCols = 32;      // match kernel: anchor columns (cell * n_box + k) per tile

@@ -39,11 +39,13 @@ def parse_args():
     ap.add_argument("--ratios", default="config", choices=["config", "model"])
     ap.add_argument("--score-thr", type=float, default=0.05)
     ap.add_argument("--stress", action="store_true", help="256 ground-truth boxes in every image")
-    ap.add_argument("--streams", type=int, default=4, help="batches in flight")
+    ap.add_argument("--streams", type=int, default=8, help="batches in flight (one stream and context each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=24)
     ap.add_argument("--anchors", default="geometry", choices=["geometry", "array"],
                     help="anchors generated on the fly (default) or read from a materialised array")
+    ap.add_argument("--profile-streams", type=int, default=1,
+                    help="batches in flight under --profile-only (1: kernels back to back)")
     ap.add_argument("--profile-only", action="store_true",
                     help="few steps on one stream, no CPU baseline (for rocprofv3 runs)")
     return ap.parse_args()
@@ -260,7 +262,7 @@ def main():
     if args.gpus != world and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
     if args.profile_only:
-        args.streams = 1
+        args.streams = args.profile_streams
     wl = Workload(args, rank)
 
     if args.profile_only:

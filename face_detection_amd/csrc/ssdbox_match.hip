@@ -266,20 +266,9 @@ SSD_DEV void match_tile(const MatchArgs &p, MatchShared &sm, int m)
         ah = anc.w;
     }
 
-    // transform_center_to_corner, utils/box_utils.py:177-179
     const float ahw = aw / 2.0f, ahh = ah / 2.0f;
-    ax0 = acx - ahw;
-    ax1 = acx + ahw;
-    const float a_w = clip0(ax1 - ax0, p.max_size);
-#pragma unroll
-    for (int i = 0; i < R; ++i) {
-        ay0[i] = acy[i] - ahh;
-        ay1[i] = acy[i] + ahh;
-        a_area[i] = a_w * clip0(ay1[i] - ay0[i], p.max_size);
-    }
-
     if (!GEOM) {
-        float lo_x = ax0, lo_y = ay0[0], hi_x = ax1, hi_y = ay1[0];
+        float lo_x = acx - ahw, lo_y = acy[0] - ahh, hi_x = acx + ahw, hi_y = acy[0] + ahh;
         for (int o = 32; o > 0; o >>= 1) {
             lo_x = fminf(lo_x, __shfl_xor(lo_x, o));
             lo_y = fminf(lo_y, __shfl_xor(lo_y, o));
@@ -298,10 +287,7 @@ SSD_DEV void match_tile(const MatchArgs &p, MatchShared &sm, int m)
         ex1 = fmaxf(fmaxf(sm.ext[2][0], sm.ext[2][1]), fmaxf(sm.ext[2][2], sm.ext[2][3]));
         ey1 = fmaxf(fmaxf(sm.ext[3][0], sm.ext[3][1]), fmaxf(sm.ext[3][2], sm.ext[3][3]));
     }
-#pragma unroll
-    for (int i = 0; i < R; ++i)
-        if (!valid[i]) ay1[i] = -3.0e38f;  // an anchor past the edge overlaps nothing (and is never stored)
-
+ 
     float best[R];         // reduce_max / argmax over GT, first maximum wins (:66-67)
     int bidx[R];
 #pragma unroll
@@ -310,6 +296,7 @@ SSD_DEV void match_tile(const MatchArgs &p, MatchShared &sm, int m)
         bidx[i] = 0;
     }
 
+    bool touched = false;          // some box reached this wave's IoU evaluation
     int par = 0;
     for (int g0 = 0; g0 < G; g0 += kBlock, par ^= 1) {
         const int g = g0 + (int)t;
@@ -340,12 +327,27 @@ SSD_DEV void match_tile(const MatchArgs &p, MatchShared &sm, int m)
         if ((int)t < n_list) sm.key[t] = 0ull;
         __syncthreads();
 
+        // Corners and areas only where a box came near: most tiles of a fine map never get
+        // here.  transform_center_to_corner, utils/box_utils.py:177-179
+        ax0 = acx - ahw;
+        ax1 = acx + ahw;
+        const float a_w = clip0(ax1 - ax0, p.max_size);
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            ay0[i] = acy[i] - ahh;
+            ay1[i] = acy[i] + ahh;
+            a_area[i] = a_w * clip0(ay1[i] - ay0[i], p.max_size);
+            // an anchor past the edge overlaps nothing (and is never stored)
+            if (!valid[i]) ay1[i] = -3.0e38f;
+        }
+
         for (int q = 0; q < n_list; ++q) {
             const float4 gb = sm.box[q];
             // compute_iou, utils/box_utils.py:35-42; the x overlap is shared by the rows
             const float iw = vmin(ax1, gb.z) - vmax(ax0, gb.x);
             // no lane of the wave can overlap this box: every IoU is +0, nothing to update
             if (__ballot(iw > 0.0f && !(gb.w <= wy0) && !(gb.y >= wy1)) == 0ull) continue;
+            touched = true;
             // The rows are evaluated without branches (an IoU of a non-overlapping pair is
             // replaced by +0 afterwards) so that their divisions overlap.
             const float cw = vmin(iw, p.max_size);
@@ -392,6 +394,18 @@ SSD_DEV void match_tile(const MatchArgs &p, MatchShared &sm, int m)
             if (key != 0ull) atomicMax(&gkey[sm.gidx[t]], key);
         }
         __syncthreads();
+    }
+
+    // No box came near and the threshold is positive: every anchor of the wave matches box 0
+    // with IoU +0 and is a negative; its offsets are the table values.
+    if (GEOM && !touched && 0.0f < p.thr) {
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            if (valid[i])
+                store_target<YTRUE, DETAILS>(p, out_row + (long long)i * a_step, out_off, 0.0f,
+                                             make_float4(tx0, ty0[i], twh0.x, twh0.y), 0, 0.0f);
+        }
+        return;
     }
 
     // gather labels / boxes, threshold, encode every anchor (:89-96).  Loads and stores share

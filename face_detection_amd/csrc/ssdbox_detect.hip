@@ -496,15 +496,17 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float4 *__restrict__
                        (jl.z - jl.z == 0.0f) && (jl.w - jl.w == 0.0f) && iarea > 0.0f && jarea > 0.0f;
     if (!zero_suppresses && __ballot(!plain) == 0ull) {
         const bool i_ok = i < K;
-        u64 cand = 0ull;                               // lane q: earlier boxes overlapping later box q
+        // Lane j sweeps the earlier boxes for its later box.  With finite corners and positive
+        // sizes on both sides, min(a.z, b.z) - max(a.x, b.x) > 0 is a.z > b.x && b.z > a.x.
+        unsigned int cand_lo = 0u, cand_hi = 0u;       // earlier boxes overlapping later box `lane`
 #pragma unroll
         for (int q = 0; q < 64; ++q) {
-            const float4 jb = s_jbox[q];               // broadcast read
-            const float iw = vmin(ib.z, jb.z) - vmax(ib.x, jb.x);
-            const float ih = vmin(ib.w, jb.w) - vmax(ib.y, jb.y);
-            const u64 w = __ballot(iw > 0.0f && ih > 0.0f);
-            if (lane == q) cand = w;
+            const float4 a = s_ibox[q];                // broadcast read
+            const bool ov = (a.z > jl.x) & (jl.z > a.x) & (a.w > jl.y) & (jl.w > a.y);   // no short circuit
+            if (q < 32) cand_lo |= ov ? (1u << q) : 0u;
+            else cand_hi |= ov ? (1u << (q - 32)) : 0u;
         }
+        u64 cand = ((u64)cand_hi << 32) | cand_lo;
         cand &= __ballot(i_ok);
         // on the diagonal tile box q is itself lane q: bits at and above it are dropped
         if (cw == rb) cand &= (1ull << lane) - 1ull;

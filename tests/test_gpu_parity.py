@@ -129,6 +129,15 @@ def test_match_edge_cases(fda):
             assert_bits_equal(miou[b], c_iou)
             assert_bits_equal(locs[b], c_locs)
     assert midx[1][0] == 1 and conf[1][0] == 1          # untouched box claims anchor 0
+    # thresholds at and below zero make every anchor a positive, also where no box is near
+    for thr in (0.0, -1.0, 0.9999):
+        for anchors in (grid, anchors_np):
+            conf, locs = fda.match_encode_batch(anchors, gt, counts, lab, 64.0, iou_threshold=thr)
+            for b in range(4):
+                g = counts[b]
+                c_conf, c_locs = C.compute_target(anchors_np, gt[b, :g], lab[b, :g], 64.0, thr)
+                np.testing.assert_array_equal(conf[b], c_conf)
+                assert_bits_equal(locs[b], c_locs)
     with pytest.raises(ValueError):
         fda.match_encode_batch(grid, gt, np.array([2, 0, 3, 1], np.int32), lab, 64.0)
     with pytest.raises(ValueError):
@@ -301,6 +310,33 @@ def test_compute_nms_conventions(fda):
         nms(boxes, np.array([.9, .8, .7], F32), 1.0, 10)
     with pytest.raises(NotImplementedError):
         nms(many, same, 0.45, 5000)
+
+
+def test_compute_nms_mask_paths(fda):
+    """The suppression mask has a listed-pairs path and a pair-by-pair path (dense tiles,
+    boxes of zero area, non-finite corners, negative threshold): both against the oracle."""
+    nms = fda.box_utils.compute_nms
+    rng = np.random.default_rng(77)
+    # one tight cluster: every pair of a 64 x 64 tile overlaps
+    ctr = np.array([[0.5, 0.5]]) + rng.normal(0, 0.01, (700, 2))
+    wh = rng.uniform(0.2, 0.3, (700, 2))
+    dense = np.concatenate([ctr - wh / 2, ctr + wh / 2], 1).astype(F32)
+    scores = rng.uniform(0, 1, 700).astype(F32)
+    for thr in (0.45, 0.9, 0.0):
+        np.testing.assert_array_equal(nms(dense, scores, thr, 1000), C.compute_nms(dense, scores, thr, 1000))
+    # mixed: sparse boxes with some of zero area, inverted corners, NaN and infinite corners
+    boxes = clustered_boxes(rng, 900)
+    boxes[5] = [0.3, 0.3, 0.3, 0.6]
+    boxes[70] = [0.4, 0.4, 0.2, 0.2]
+    boxes[200, 2] = np.nan
+    boxes[333] = [0.1, 0.1, np.inf, 0.5]
+    boxes[640] = [-np.inf, 0.2, 0.4, 0.5]
+    scores = rng.uniform(0, 1, 900).astype(F32)
+    np.testing.assert_array_equal(nms(boxes, scores, 0.45, 1000), C.compute_nms(boxes, scores, 0.45, 1000))
+    # negative threshold: a pair that does not overlap at all suppresses too
+    sparse = clustered_boxes(rng, 300)
+    s3 = rng.uniform(0, 1, 300).astype(F32)
+    np.testing.assert_array_equal(nms(sparse, s3, -0.5, 1000), C.compute_nms(sparse, s3, -0.5, 1000))
 
 
 def test_elementwise_functions(fda):

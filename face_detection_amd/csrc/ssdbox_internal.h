@@ -14,10 +14,7 @@
 // and per-row centre tables (float32, already clipped) live in device memory because they
 // are the only part whose size grows with the image (sum of fm_w + fm_h floats).
 // ---------------------------------------------------------------------------------------
-#ifndef SSD_EXP_R                  // timing experiment only
-#define SSD_EXP_R 4
-#endif
-constexpr int kRowsPerThread = SSD_EXP_R;  // match kernel: anchors (rows of one column) per thread
+constexpr int kRowsPerThread = 4;  // match kernel: anchors (rows of one column) per thread
 constexpr int kTileRows = 8 * kRowsPerThread;   // feature-map rows per workgroup tile
 constexpr int kCoarseTileRows = 8;  // rows per tile on coarse maps (one anchor per thread)
 constexpr int kTileCols = 32;      // match kernel: anchor columns (cell * n_box + k) per tile
@@ -89,14 +86,12 @@ struct ssdbox_ctx {
     // box 0 of each image
     float *b0_tab;
     size_t b0_cap;
-    int *work_counter;             // match kernel's item tickets; zero between calls
 
     // detection scratch
-    unsigned long long *cand;      // (batch, N) candidate keys
+    unsigned long long *cand;      // (batch, segments * 256) candidate keys, per-wave segments
     size_t cand_cap;
-    int *cand_count;               // (batch); zero between calls
+    int *cand_count;               // (batch, segments) candidates per segment
     size_t count_cap;
-    bool count_dirty;
     float4 *sboxes;                // (batch, LIMIT) decoded boxes in rank order
     float *sscores;
     int *sidx;

@@ -58,22 +58,30 @@ def relaunch_under_torchrun(args):
     return subprocess.call(cmd)
 
 
+def make_inputs(args, rank):
+    """Synthetic batch of this rank as numpy arrays (no GPU involved)."""
+    import numpy as np
+    from face_detection_amd import synthetic as S
+    cfg = S.reference_ssd_config(args.size, args.ratios)
+    rng = np.random.default_rng(1000 + rank)
+    gt_boxes, gt_labels, gt_counts = S.make_ground_truth(rng, args.batch, args.size, gmax=args.gmax,
+                                                         stress=args.stress)
+    y_pred = S.make_head_outputs(rng, cfg, gt_boxes, gt_counts)
+    return cfg, gt_boxes, gt_labels, gt_counts, y_pred
+
+
 class Workload:
     """Device-resident inputs and per-stream outputs/contexts for one rank."""
 
-    def __init__(self, args, rank):
+    def __init__(self, args, rank, inputs=None):
         import numpy as np
         import torch
-        from face_detection_amd import _lib, synthetic as S
+        from face_detection_amd import _lib
         from face_detection_amd.runtime import Context, geometry_for
         self.torch, self.np, self.lib_mod = torch, np, _lib
         self.lib = _lib.load()
         self.args = args
-        self.cfg = S.reference_ssd_config(args.size, args.ratios)
-        rng = np.random.default_rng(1000 + rank)
-        self.gt_boxes, self.gt_labels, self.gt_counts = S.make_ground_truth(
-            rng, args.batch, args.size, gmax=args.gmax, stress=args.stress)
-        self.y_pred = S.make_head_outputs(rng, self.cfg, self.gt_boxes, self.gt_counts)
+        self.cfg, self.gt_boxes, self.gt_labels, self.gt_counts, self.y_pred = inputs or make_inputs(args, rank)
         dev = torch.device("cuda", torch.cuda.current_device())
         self.geom = geometry_for(self.cfg, dev.index)
         self.A = self.geom.num_anchors
@@ -177,33 +185,90 @@ def stage_times(wl, steps):
     return {k: (ms / n * 1e3) for k, (ms, n) in t.items() if n}       # microseconds
 
 
-def cpu_baseline(wl, n_images):
-    """The numpy restatement of the reference's TF-eager algorithm (materialised (A,G) IoU,
-    O(K^3) NMS loop, Python anchor loop), one core, on the first images of this batch."""
-    np = wl.np
+_CPU = {}      # inputs of the CPU baseline, set before the worker pool forks
+
+
+def _cpu_one(b, keep_outputs=False):
+    """One image through the numpy restatement of the reference's TF-eager algorithm."""
     from oracle import box_oracle as O
+    cfg, gt_boxes, gt_labels, gt_counts, y_pred, anchors, size, thr = _CPU["in"]
+    g = int(gt_counts[b])
     t0 = time.perf_counter()
-    anchors = O.generate_anchors(wl.cfg)                  # once per dataset on the training side
+    conf, locs = O.compute_target(anchors, gt_boxes[b, :g], gt_labels[b, :g], float(size))
+    t1 = time.perf_counter()
+    O.generate_anchors(cfg)                               # inference.py:44 regenerates per image
+    dets, keep = O.postprocess(y_pred[b], anchors, thr, 1.0, 1.0, 0.45, 1000)
+    t2 = time.perf_counter()
+    return (t1 - t0, t2 - t1, (conf, locs, dets, keep) if keep_outputs else None)
+
+
+def cpu_baseline(args, inputs, n_images, workers=6):
+    """The numpy restatement of the reference's TF-eager algorithm (materialised (A,G) IoU,
+    O(K^3) NMS loop, Python anchor loop) on the first images of this batch: one core (the
+    reported value), then a pool of `workers` processes as in the reference's
+    num_parallel_calls=6 (utils/datasets.py:42).  Runs before the GPU is touched (the pool
+    forks).  Also returns the per-image outputs for the parity check of the GPU results."""
+    import multiprocessing as mp
+    from oracle import box_oracle as O
+    cfg, gt_boxes, gt_labels, gt_counts, y_pred = inputs
+    t0 = time.perf_counter()
+    anchors = O.generate_anchors(cfg)                     # once per dataset on the training side
     t_anchor = time.perf_counter() - t0
-    n = min(n_images, wl.args.batch)
+    _CPU["in"] = (cfg, gt_boxes, gt_labels, gt_counts, y_pred, anchors, args.size, args.score_thr)
+    n = min(n_images, args.batch)
     t_match = t_det = 0.0
+    outputs = []
     for b in range(n):
-        g = int(wl.gt_counts[b])
-        t0 = time.perf_counter()
-        O.compute_target(anchors, wl.gt_boxes[b, :g], wl.gt_labels[b, :g], float(wl.args.size))
-        t_match += time.perf_counter() - t0
-        t0 = time.perf_counter()
-        O.generate_anchors(wl.cfg)                        # inference.py:44 regenerates per image
-        O.postprocess(wl.y_pred[b], anchors, wl.args.score_thr, 1.0, 1.0, 0.45, 1000)
-        t_det += time.perf_counter() - t0
+        tm, td, out = _cpu_one(b, keep_outputs=True)
+        t_match += tm
+        t_det += td
+        outputs.append(out)
     per_image = (t_match + t_det) / n
-    return {
+    pool_rate = None
+    try:
+        with mp.get_context("fork").Pool(workers) as pool:
+            t0 = time.perf_counter()
+            pool.map(_cpu_one, range(n), chunksize=1)
+            pool_rate = n / (time.perf_counter() - t0)
+    except Exception as e:                                # the figure is optional
+        print("cpu pool baseline skipped: %r" % (e,), file=sys.stderr)
+    res = {
         "value": 1.0 / per_image, "unit": "images/sec", "cores": 1, "kind": "port",
         "sample": "%d images of this batch (G=%s): numpy literal oracle, match+encode %.3f s/img, "
                   "anchors+decode+NMS %.3f s/img, one-off anchor generation %.2f s"
-                  % (n, [int(x) for x in wl.gt_counts[:n]], t_match / n, t_det / n, t_anchor),
+                  % (n, [int(x) for x in gt_counts[:n]], t_match / n, t_det / n, t_anchor),
         "match_encode_images_per_s": n / t_match, "decode_nms_images_per_s": n / t_det,
+        "pool": {"workers": workers, "images_per_s": pool_rate},
     }
+    return res, outputs
+
+
+def parity_check(wl, outputs):
+    """GPU results of the bench batch against the CPU baseline's outputs for the same images:
+    positives mask, kept indices and counts exact; floats within rtol 1e-5 / atol 1e-6 (the
+    numpy oracle's exp/log differ from the kernels' by a few ULP)."""
+    np, torch = wl.np, wl.torch
+    slot = wl.slots[0]
+    wl.match(slot)
+    wl.detect(slot)
+    torch.cuda.synchronize()
+    n = len(outputs)
+    conf = slot["conf"][:n].cpu().numpy()
+    locs = slot["locs"][:n].cpu().numpy()
+    dets = slot["dets"][:n].cpu().numpy()
+    keep = slot["keep"][:n].cpu().numpy()
+    count = slot["count"][:n].cpu().numpy()
+    ok_match = ok_nms = ok_float = 0
+    for b, (c_conf, c_locs, c_dets, c_keep) in enumerate(outputs):
+        k = len(c_keep)
+        m_ok = np.array_equal(conf[b], c_conf)
+        n_ok = int(count[b]) == k and np.array_equal(keep[b, :k], c_keep)
+        f_ok = np.allclose(locs[b], c_locs, rtol=1e-5, atol=1e-6) and n_ok and \
+            np.allclose(dets[b, :k], np.asarray(c_dets, np.float32).reshape(k, 6), rtol=1e-5, atol=1e-6)
+        ok_match += int(m_ok)
+        ok_nms += int(n_ok)
+        ok_float += int(f_ok)
+    return {"images": n, "match_mask_exact": ok_match, "nms_kept_exact": ok_nms, "floats_close": ok_float}
 
 
 def pcie_times(wl, reps=5):
@@ -255,6 +320,13 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(relaunch_under_torchrun(args))
 
+    # the CPU baseline forks a worker pool: it runs before anything initialises the GPU
+    inputs = cpu = cpu_outputs = None
+    single = int(os.environ.get("WORLD_SIZE", "1")) == 1
+    if single and not args.no_cpu_baseline and not args.profile_only:
+        inputs = make_inputs(args, 0)
+        cpu, cpu_outputs = cpu_baseline(args, inputs, args.cpu_images)
+
     import torch
     import torch.distributed as dist
     from face_detection_amd import dist as fdist
@@ -263,7 +335,7 @@ def main():
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
     if args.profile_only:
         args.streams = args.profile_streams
-    wl = Workload(args, rank)
+    wl = Workload(args, rank, inputs)
 
     if args.profile_only:
         for i in range(args.warmup + args.steps):
@@ -344,8 +416,9 @@ def main():
         step_s = elapsed / args.steps
         pcie["images_per_s_with_transfers_serial"] = args.batch / (step_s + (pcie["h2d_ms"] + pcie["d2h_ms"]) * 1e-3)
         out["pcie"] = pcie
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(wl, args.cpu_images)
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+            out["parity"] = parity_check(wl, cpu_outputs)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

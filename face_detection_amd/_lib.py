@@ -57,6 +57,8 @@ SIGNATURES = {
     "ssdbox_decode": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _f, _f, _vp]),
     "ssdbox_corner_to_center": (_i, [_vp, _vp, _i64, _vp]),
     "ssdbox_center_to_corner": (_i, [_vp, _vp, _i64, _vp]),
+    "ssdbox_prepare_gt": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "ssdbox_widerface_rows": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
     "ssdbox_selftest": (_i, [_vp, _pf, _pf, _pf, _pf, _i]),
 }
 

@@ -112,3 +112,59 @@ def decode_nms_batch(anchors, y_pred, score_threshold, nms_threshold=0.45, limit
         ctx.handle, geom, _ptr(anc), A, _ptr(y), B, float(score_threshold), float(nms_threshold),
         limit, _ptr(wh), _ptr(dets), _ptr(keep), _ptr(count)))
     return from_device(dets, family), from_device(keep, family), from_device(count, family)
+
+
+def prepare_gt_batch(raw_xywh, gt_count, img_wh, target_hw, shrink=None, context=None):
+    """Annotation boxes of a batch to the normalised corners match_encode_batch takes.
+
+    raw_xywh (B,G,4) WiderFace (x, y, w, h) in pixels, zero padded; gt_count (B,); img_wh (B,2)
+    int original (width, height); target_hw (height, width) of the network input; shrink None
+    or (B,4) int rows [h2, w2, h_off, w_off] of random_shrink (h2 <= 0: that image was not
+    shrunk).  Equals, image by image, reference utils/datasets.py:131-140 followed by the box
+    halves of utils/transforms.py:60-63 and :28-33.  Returns (B,G,4) float32, zero after the
+    count.
+    """
+    torch = require_gpu()
+    device = torch.cuda.current_device()
+    ctx = context or default_context(device)
+    raw, family = to_device(raw_xywh, np.float32, device)
+    if raw.dim() != 3 or raw.shape[2] != 4:
+        raise ValueError("raw_xywh must have shape (B, G, 4), got %s" % (tuple(raw.shape),))
+    B, G = int(raw.shape[0]), int(raw.shape[1])
+    counts, _ = to_device(gt_count, np.int32, device)
+    wh, _ = to_device(img_wh, np.int32, device)
+    if tuple(counts.shape) != (B,) or tuple(wh.shape) != (B, 2):
+        raise ValueError("gt_count must have shape (%d,) and img_wh (%d, 2)" % (B, B))
+    if B and int(wh.min()) < 1:
+        raise ValueError("image sizes must be positive")
+    sh = None
+    if shrink is not None:
+        sh, _ = to_device(shrink, np.int32, device)
+        if tuple(sh.shape) != (B, 4):
+            raise ValueError("shrink must have shape (%d, 4)" % B)
+    out = torch.empty((B, G, 4), dtype=torch.float32, device=raw.device)
+    if B and G:
+        _lib.check(ctx.lib.ssdbox_prepare_gt(ctx.handle, _ptr(raw), _ptr(counts), _ptr(wh), _ptr(sh), B, G,
+                                             int(target_hw[0]), int(target_hw[1]), _ptr(out)))
+    return from_device(out, family)
+
+
+def widerface_rows_batch(dets, count, context=None):
+    """Detections of decode_nms_batch (pixels of the original image) to the integer rows of
+    WiderFace result files, reference evaluation.py:69-76.  dets (B,limit,6), count (B,) ->
+    (xywh (B,limit,4) int32, scores (B,limit)), zero after the count."""
+    torch = require_gpu()
+    device = torch.cuda.current_device()
+    ctx = context or default_context(device)
+    d, family = to_device(dets, np.float32, device)
+    if d.dim() != 3 or d.shape[2] != 6:
+        raise ValueError("dets must have shape (B, limit, 6), got %s" % (tuple(d.shape),))
+    B, limit = int(d.shape[0]), int(d.shape[1])
+    c, _ = to_device(count, np.int32, device)
+    if tuple(c.shape) != (B,):
+        raise ValueError("count must have shape (%d,)" % B)
+    xywh = torch.empty((B, limit, 4), dtype=torch.int32, device=d.device)
+    scores = torch.empty((B, limit), dtype=torch.float32, device=d.device)
+    if B and limit:
+        _lib.check(ctx.lib.ssdbox_widerface_rows(ctx.handle, _ptr(d), _ptr(c), B, limit, _ptr(xywh), _ptr(scores)))
+    return from_device(xywh, family), from_device(scores, family)

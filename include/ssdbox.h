@@ -156,6 +156,28 @@ int ssdbox_decode(ssdbox_ctx *ctx, const ssdbox_geom *geom, const float *d_ancho
 int ssdbox_corner_to_center(ssdbox_ctx *ctx, const float *d_in, int64_t n, float *d_out);
 int ssdbox_center_to_corner(ssdbox_ctx *ctx, const float *d_in, int64_t n, float *d_out);
 
+/* ---- the data formats either side of the path ------------------------------------------ */
+
+/* Ground truth as the annotation files store it to what ssdbox_match_encode takes, for a
+ * batch: utils/datasets.py:131-140 ((x, y, w, h) pixels -> corners, -1, divide by the image
+ * size), then the box half of random_shrink (utils/transforms.py:60-63) where d_shrink
+ * (batch,4) int32 rows [h2, w2, h_off, w_off] has h2 > 0 (d_shrink may be NULL: no image was
+ * shrunk), then the box half of reize_with_pad (utils/transforms.py:28-33) for a
+ * target_h x target_w network input.  d_raw_xywh (batch,gmax,4), d_gt_count (batch),
+ * d_img_wh (batch,2) int32 original (width, height) -> d_boxes (batch,gmax,4) normalised
+ * corners, zero after the count.  float32 operation for operation as the reference's numpy
+ * code evaluates them. */
+int ssdbox_prepare_gt(ssdbox_ctx *ctx, const float *d_raw_xywh, const int32_t *d_gt_count,
+                      const int32_t *d_img_wh, const int32_t *d_shrink, int batch, int gmax,
+                      int target_h, int target_w, float *d_boxes);
+
+/* Detection rows of ssdbox_decode_nms (pixels of the original image) to the integer rows of a
+ * WiderFace result file, evaluation.py:69-76: corners truncated toward zero, +1, then
+ * (xmin, ymin, xmax - xmin, ymax - ymin).  d_dets (batch,limit,6), d_count (batch) ->
+ * d_xywh (batch,limit,4) int32 and d_scores (batch,limit), zero after the count. */
+int ssdbox_widerface_rows(ssdbox_ctx *ctx, const float *d_dets, const int32_t *d_count, int batch,
+                          int limit, int32_t *d_xywh, float *d_scores);
+
 /* Device self-checks of the building blocks (wave reductions, exp/log against the values
  * in expect_log/expect_exp for the host inputs x_log/x_exp, n each).  Blocks the host.
  * Returns 0 when every check passes. */

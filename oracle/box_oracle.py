@@ -251,3 +251,61 @@ def postprocess(y_pred_image, anchors, conf_thresh, img_width=1.0, img_height=1.
     out[:, 3] *= F32(img_height)
     dets = np.concatenate([np.ones((len(sel), 1), F32), scores[sel][:, None], out], axis=1)
     return dets.astype(F32), sel.astype(np.int32)
+
+
+# --------------------------------------------------------------------------------------
+# The data formats either side of the path (test infrastructure like the rest of this file).
+# The reference evaluates these lines on float32 numpy arrays against Python ints and int32
+# scalars; with the numpy of its time (value-based casting) every operation stays float32.
+# The scalars are converted to float32 explicitly here so that the result does not depend on
+# the numpy version running the oracle.
+# --------------------------------------------------------------------------------------
+def prepare_gt(raw_xywh, img_w, img_h, target_h, target_w, shrink=None):
+    """WiderFace (x, y, w, h) pixel boxes of one image -> normalised corners as compute_target
+    receives them: utils/datasets.py:131-140, then (shrink = (h2, w2, h_off, w_off)) the box
+    half of random_shrink, utils/transforms.py:60-63, then the box half of reize_with_pad,
+    utils/transforms.py:28-33."""
+    boxes = np.array(raw_xywh, dtype=F32).reshape(-1, 4)
+    boxes[:, 2] = boxes[:, 0] + boxes[:, 2]
+    boxes[:, 3] = boxes[:, 1] + boxes[:, 3]
+    boxes -= F32(1)
+    w, h = F32(img_w), F32(img_h)
+    boxes[:, 0] = boxes[:, 0] / w
+    boxes[:, 2] = boxes[:, 2] / w
+    boxes[:, 1] = boxes[:, 1] / h
+    boxes[:, 3] = boxes[:, 3] / h
+    if shrink is not None:
+        h2, w2, h_off, w_off = (F32(v) for v in shrink)
+        boxes[:, 0] = (boxes[:, 0] * w2 + w_off - F32(1)) / w
+        boxes[:, 1] = (boxes[:, 1] * h2 + h_off - F32(1)) / h
+        boxes[:, 2] = (boxes[:, 2] * w2 + w_off - F32(1)) / w
+        boxes[:, 3] = (boxes[:, 3] * h2 + h_off - F32(1)) / h
+    h1, w1 = int(img_h), int(img_w)
+    if h1 / w1 < target_h / target_w:
+        den, num = F32(target_h * w1), F32(h1 * target_w)
+        boxes[:, 1] = (boxes[:, 1] - F32(0.5)) / den * num + F32(0.5)
+        boxes[:, 3] = (boxes[:, 3] - F32(0.5)) / den * num + F32(0.5)
+    else:
+        den, num = F32(target_w * h1), F32(w1 * target_h)
+        boxes[:, 0] = (boxes[:, 0] - F32(0.5)) / den * num + F32(0.5)
+        boxes[:, 2] = (boxes[:, 2] - F32(0.5)) / den * num + F32(0.5)
+    return boxes
+
+
+def widerface_rows(preds):
+    """evaluation.py:69-76: (n,6) detection rows in pixels -> (n,4) integer (x, y, w, h)."""
+    preds = np.asarray(preds, dtype=np.float64).reshape(-1, 6)
+    boxes = preds[:, 2:6].astype(np.int64)
+    boxes += 1
+    boxes[:, 2] = boxes[:, 2] - boxes[:, 0]
+    boxes[:, 3] = boxes[:, 3] - boxes[:, 1]
+    return boxes, preds[:, 1]
+
+
+def widerface_lines(name, preds):
+    """evaluation.py:70,77-78: the text of one result file."""
+    boxes, scores = widerface_rows(preds)
+    lines = [name + "\n", "%d\n" % len(boxes)]
+    for box, score in zip(boxes, scores):
+        lines.append("%d %d %d %d %.3f\n" % (box[0], box[1], box[2], box[3], score))
+    return "".join(lines)

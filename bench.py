@@ -136,6 +136,30 @@ class Workload:
         self.match(slot)
         self.detect(slot)
 
+    def setup_loss(self):
+        """Buffers for the loss figure: y_true of this batch in the training layout (from the
+        fused match kernel), loss, mined-negative mask and gradient."""
+        torch, a = self.torch, self.args
+        slot = self.slots[0]
+        B, A = a.batch, self.A
+        self.y_true = torch.empty((B, A, 6), dtype=torch.float32, device=slot["conf"].device)
+        rc = self.lib.ssdbox_match_encode_ytrue(
+            slot["ctx"].handle, self.g_handle, self.a_ptr, self.A, self._p(self.d_boxes),
+            self._p(self.d_labels), self._p(self.d_counts), a.batch, a.gmax, float(a.size), 0.5,
+            self._p(self.y_true))
+        if rc != 0:
+            self.lib_mod.check(rc)
+        self.loss_total = torch.empty((B,), dtype=torch.float32, device=self.y_true.device)
+        self.loss_grad = torch.empty((B, A, 6), dtype=torch.float32, device=self.y_true.device)
+        torch.cuda.synchronize()
+
+    def loss(self, slot, with_grad=True):
+        rc = self.lib.ssdbox_ssd_loss(
+            slot["ctx"].handle, self._p(self.y_true), self._p(self.d_ypred), self.args.batch, self.A,
+            3, 0, 1.0, self._p(self.loss_total), None, self._p(self.loss_grad) if with_grad else None)
+        if rc != 0:
+            self.lib_mod.check(rc)
+
     def algorithmic_bytes(self):
         """Per batch: match+encode reads 20 B per GT box and writes 20 B per anchor;
         decode+NMS reads the 24 B head row of every anchor and writes 24 B per kept box
@@ -352,6 +376,12 @@ def main():
     t_match = timed_loop(torch, dist, world, lambda i: wl.match(wl.slots[i % nslots]), args.steps, 5)
     t_det = timed_loop(torch, dist, world, lambda i: wl.detect(wl.slots[i % nslots]), args.steps, 5)
 
+    # the training-side consumer of the targets: SSD loss with hard-negative mining, value and
+    # gradient (not part of `value`)
+    wl.setup_loss()
+    t_loss = timed_loop(torch, dist, world, lambda i: wl.loss(wl.slots[0]), max(args.steps // 4, 10), 5)
+    n_loss = max(args.steps // 4, 10)
+
     # the optional collective, outside the timed loop: every rank receives all detections
     allgather_ms = None
     if world > 1:
@@ -399,6 +429,8 @@ def main():
             },
             "match_encode_images_per_s": args.batch * args.steps * world / t_match,
             "decode_nms_images_per_s": args.batch * args.steps * world / t_det,
+            "ssd_loss_fwd_bwd_images_per_s": args.batch * n_loss * world / t_loss,
+            "ssd_loss_fwd_bwd_ms": t_loss / n_loss * 1e3,
             "kernel_us": {k: round(v, 2) for k, v in stages.items()},
             "roofline": {
                 "bound": "hbm", "kernel": dominant + "_kernel",

@@ -16,8 +16,9 @@ ERR_HIP = -2
 ERR_NOMEM = -3
 ERR_UNSUPPORTED = -4
 
-NUM_STAGES = 8
-STAGE_NAMES = ("match", "force", "select", "topk", "nms_mask", "nms_scan", "elementwise", "shapes")
+NUM_STAGES = 9
+STAGE_NAMES = ("match", "force", "select", "topk", "nms_mask", "nms_scan", "elementwise", "shapes",
+               "loss")
 MAX_NMS_LIMIT = 1024
 MAX_GT = 4096
 MAX_LAYERS = 8
@@ -59,6 +60,7 @@ SIGNATURES = {
     "ssdbox_center_to_corner": (_i, [_vp, _vp, _i64, _vp]),
     "ssdbox_prepare_gt": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ssdbox_widerface_rows": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "ssdbox_ssd_loss": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _f, _vp, _vp, _vp]),
     "ssdbox_selftest": (_i, [_vp, _pf, _pf, _pf, _pf, _i]),
 }
 

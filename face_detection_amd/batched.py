@@ -168,3 +168,36 @@ def widerface_rows_batch(dets, count, context=None):
     if B and limit:
         _lib.check(ctx.lib.ssdbox_widerface_rows(ctx.handle, _ptr(d), _ptr(c), B, limit, _ptr(xywh), _ptr(scores)))
     return from_device(xywh, family), from_device(scores, family)
+
+
+def ssd_loss_batch(y_true, y_pred, neg_pos_ratio=3, n_neg_min=0, alpha=1.0, return_keep=False,
+                   return_grad=False, context=None):
+    """SSD loss with hard-negative mining, reference utils/losses.py:97-181 (SSDLoss.call).
+
+    y_true, y_pred (B,A,6) = [background, face, 4 offsets].  Returns the (B,) per-image loss;
+    with return_keep also the (B,A) bool mask of mined negatives; with return_grad also the
+    (B,A,6) gradient of mean(loss) with respect to y_pred (what Keras back-propagates).
+    """
+    torch = require_gpu()
+    device = torch.cuda.current_device()
+    ctx = context or default_context(device)
+    yt, family = to_device(y_true, np.float32, device)
+    yp, _ = to_device(y_pred, np.float32, device)
+    if yt.dim() != 3 or yt.shape[2] != 6 or tuple(yt.shape) != tuple(yp.shape):
+        raise ValueError("y_true and y_pred must both have shape (B, A, 6), got %s and %s"
+                         % (tuple(yt.shape), tuple(yp.shape)))
+    B, A = int(yt.shape[0]), int(yt.shape[1])
+    if B == 0 or A == 0:
+        raise ValueError("empty batch")
+    total = torch.empty((B,), dtype=torch.float32, device=yt.device)
+    keep = torch.empty((B, A), dtype=torch.uint8, device=yt.device) if return_keep else None
+    grad = torch.empty((B, A, 6), dtype=torch.float32, device=yt.device) if return_grad else None
+    _lib.check(ctx.lib.ssdbox_ssd_loss(ctx.handle, _ptr(yt), _ptr(yp), B, A, int(neg_pos_ratio), int(n_neg_min),
+                                       float(alpha), _ptr(total), _ptr(keep), _ptr(grad)))
+    res = (from_device(total, family),)
+    if return_keep:
+        k = from_device(keep, family)
+        res += (k.bool() if family == "torch" else (k != 0),)
+    if return_grad:
+        res += (from_device(grad, family),)
+    return res[0] if len(res) == 1 else res

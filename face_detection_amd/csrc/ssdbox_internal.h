@@ -87,6 +87,12 @@ struct ssdbox_ctx {
     float *b0_tab;
     size_t b0_cap;
 
+    // loss scratch: rank keys of the negative log-losses; histograms, state, sums, chunk counts
+    unsigned *loss_key;
+    size_t loss_key_cap;
+    unsigned char *loss_small;
+    size_t loss_small_cap;
+
     // detection scratch
     unsigned long long *cand;      // (batch, segments * 256) candidate keys, per-wave segments
     size_t cand_cap;

@@ -1,0 +1,449 @@
+// SSD loss with hard-negative mining for a batch (reference utils/losses.py:97-181), forward
+// value per image, the mined-negative mask and the gradient of the batch mean with respect to
+// y_pred (what TensorFlow's autodiff derives: the mask and the counts are constants).
+// Rows are [background, face, 4 offsets] for y_true and y_pred alike.
+//
+// The top-k of the reference runs over all batch * anchors negative log-losses at once
+// (utils/losses.py:149-153).  Here it is a radix select on the 32-bit rank key of the value
+// (larger key = larger value, NaN last, -0 = +0): three histogram passes (11 + 11 + 10 bits)
+// find the k-th largest key T; keys above T are kept, keys equal to T in ascending index order
+// until k is reached (tf.nn.top_k ranks equal values by index), which takes an ordered count
+// of the keys equal to T per workgroup chunk and a scan over the chunks.
+//
+//   pass1   per anchor: log-loss, smooth-L1, key -> scratch; per-image sums (double atomics);
+//           positives and nonzero negative losses counted; histogram of the top 11 key bits
+//   scan    k = min(max(ratio * n_pos, n_neg_min), n_nonzero); the digit where the count from
+//           the top crosses k                                   (again after each histogram)
+//   hist    histogram of the next digit among the keys that share the prefix (twice)
+//   count   keys equal to T per chunk, then an exclusive scan over the chunks
+//   final   mask, mined-negative sums, gradient
+//   finish  (pos + neg + alpha * loc) / max(1, n_pos) * batch per image
+#include "ssdbox_internal.h"
+
+namespace {
+
+typedef unsigned long long u64;
+
+constexpr int kLB = 256;               // threads per workgroup
+constexpr int kPerThread = 8;          // anchors per thread and chunk
+constexpr int kBins = 2048;
+
+struct LossState {
+    double n_pos;                      // sum of the positives column (utils/losses.py:112)
+    u64 n_nonzero;                     // nonzero negative log-losses (:123)
+    long long k;                       // negatives to keep (:135-136)
+    long long k_rem;                   // of which still to find inside the current prefix
+    unsigned prefix, pmask;            // key bits fixed so far
+    unsigned threshold;                // key of the k-th largest value
+    unsigned need_eq, count_eq;        // keys equal to it: to keep / present
+};
+
+struct LossArgs {
+    const float *y_true;
+    const float *y_pred;
+    int batch;
+    int num_anchors;
+    int blocks_per_image;
+    int chunk;                         // anchors per workgroup, a multiple of kLB
+    int neg_pos_ratio, n_neg_min;
+    float alpha;
+    unsigned *key;                     // (batch * anchors) rank keys of the negative log-losses
+    unsigned *hist;                    // (3, kBins)
+    LossState *state;
+    double *sums;                      // (batch, 4): positive log-loss, smooth-L1, mined log-loss
+    unsigned *chunk_eq;                // (batch * blocks_per_image) keys equal to the threshold
+    float *total;                      // (batch)
+    unsigned char *keep;               // (batch, anchors) or NULL
+    float *grad;                       // (batch, anchors, 6) or NULL
+};
+
+struct Row {
+    float2 c, xy, wh;
+};
+
+SSD_DEV Row load_row(const float *base, long long i)
+{
+    const float2 *p = reinterpret_cast<const float2 *>(base + i * 6);
+    Row r;
+    r.c = p[0];
+    r.xy = p[1];
+    r.wh = p[2];
+    return r;
+}
+
+// utils/losses.py:78-81
+SSD_DEV float class_loss(const Row &t, const Row &p)
+{
+    const float l0 = ssd_logf(fmaxf(p.c.x, 1e-15f)), l1 = ssd_logf(fmaxf(p.c.y, 1e-15f));
+    return -(t.c.x * l0 + t.c.y * l1);
+}
+
+SSD_DEV float smooth_l1_term(float t, float p)
+{
+    const float d = t - p;
+    const float a = fabsf(d);
+    return a < 1.0f ? 0.5f * (d * d) : a - 0.5f;
+}
+
+// utils/losses.py:58-61
+SSD_DEV float loc_loss(const Row &t, const Row &p)
+{
+    float s = 0.0f;
+    s = s + smooth_l1_term(t.xy.x, p.xy.x);
+    s = s + smooth_l1_term(t.xy.y, p.xy.y);
+    s = s + smooth_l1_term(t.wh.x, p.wh.x);
+    s = s + smooth_l1_term(t.wh.y, p.wh.y);
+    return s;
+}
+
+SSD_DEV double block_sum(double v, double *s_red)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double r = 0.0;
+#pragma unroll
+    for (int w = 0; w < kLB / 64; ++w) r += s_red[w];
+    return r;
+}
+
+SSD_DEV void flush_hist(const unsigned *s_hist, unsigned *g_hist)
+{
+    for (int b = threadIdx.x; b < kBins; b += kLB) {
+        const unsigned c = s_hist[b];
+        if (c != 0u) atomicAdd(&g_hist[b], c);
+    }
+}
+
+// grid (blocks_per_image, batch)
+__global__ __launch_bounds__(kLB) void loss_pass1_kernel(const LossArgs p)
+{
+    __shared__ unsigned s_hist[kBins];
+    __shared__ double s_red[kLB / 64];
+    const int t = threadIdx.x;
+    const int img = blockIdx.y;
+    for (int b = t; b < kBins; b += kLB) s_hist[b] = 0u;
+    __syncthreads();
+    const int a0 = blockIdx.x * p.chunk;
+    const int a1 = min(a0 + p.chunk, p.num_anchors);
+    double pos_cls = 0.0, loc_s = 0.0, n_pos = 0.0;
+    unsigned nonzero = 0;
+    for (int a = a0 + t; a < a1; a += kLB) {
+        const long long i = (long long)img * p.num_anchors + a;
+        const Row yt = load_row(p.y_true, i), yp = load_row(p.y_pred, i);
+        const float cls = class_loss(yt, yp);
+        const float loc = loc_loss(yt, yp);
+        const float pos = yt.c.y;                          // :109 (one class besides background)
+        pos_cls += (double)(cls * pos);                    // :117
+        loc_s += (double)(loc * pos);                      // :170
+        n_pos += (double)pos;                              // :112
+        const float neg_all = cls * yt.c.x;                // :122
+        nonzero += (neg_all != 0.0f) ? 1u : 0u;            // :123 (NaN counts, -0 does not)
+        const unsigned key = score_key(neg_all);
+        p.key[i] = key;
+        atomicAdd(&s_hist[key >> 21], 1u);
+    }
+    pos_cls = block_sum(pos_cls, s_red);
+    loc_s = block_sum(loc_s, s_red);
+    n_pos = block_sum(n_pos, s_red);
+    const double nz = block_sum((double)nonzero, s_red);
+    if (t == 0) {
+        if (pos_cls != 0.0) atomicAdd(&p.sums[4 * img + 0], pos_cls);
+        if (loc_s != 0.0) atomicAdd(&p.sums[4 * img + 1], loc_s);
+        if (n_pos != 0.0) atomicAdd(&p.state->n_pos, n_pos);
+        if (nz != 0.0) atomicAdd(&p.state->n_nonzero, (u64)nz);
+    }
+    __syncthreads();
+    flush_hist(s_hist, p.hist);
+}
+
+// One workgroup of 1024 threads: the digit of pass `pass` where the count from the top
+// crosses what is still to be found.
+__global__ __launch_bounds__(1024) void loss_scan_kernel(const LossArgs p, int pass)
+{
+    __shared__ unsigned s_wtot[16];
+    __shared__ unsigned s_sel[3];
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    LossState *st = p.state;
+    long long k_rem;
+    if (pass == 0) {
+        long long k = (long long)p.neg_pos_ratio * (long long)st->n_pos;      // :135-136
+        if (k < p.n_neg_min) k = p.n_neg_min;
+        if (k > (long long)st->n_nonzero) k = (long long)st->n_nonzero;
+        k_rem = k;
+        if (t == 0) {
+            st->k = k;
+            st->prefix = 0u;
+            st->pmask = 0u;
+        }
+    } else {
+        k_rem = st->k_rem;
+    }
+    if (k_rem <= 0) {                  // nothing to keep (:163 and k == 0)
+        if (t == 0) {
+            st->k_rem = 0;
+            st->need_eq = 0u;
+            st->count_eq = 0u;
+            st->threshold = 0xFFFFFFFFu;
+        }
+        return;
+    }
+    const int shift = pass == 0 ? 21 : (pass == 1 ? 10 : 0);
+    const unsigned dmask = pass == 2 ? 0x3FFu : 0x7FFu;
+    const unsigned *hist = p.hist + pass * kBins;
+    const unsigned h0 = hist[2 * t], h1 = hist[2 * t + 1];
+    const unsigned pair = h0 + h1;
+    unsigned incl = pair;              // suffix sum over this wave's higher lanes
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned v = __shfl_down(incl, o);
+        if (lane + o < 64) incl += v;
+    }
+    if (lane == 0) s_wtot[wave] = incl;
+    __syncthreads();
+    unsigned above1 = incl - pair;     // keys in digits above 2t+1
+    for (int w = wave + 1; w < 16; ++w) above1 += s_wtot[w];
+    const unsigned above0 = above1 + h1;
+    if ((long long)above1 < k_rem && (long long)above1 + h1 >= k_rem) {
+        s_sel[0] = 2 * t + 1;
+        s_sel[1] = above1;
+        s_sel[2] = h1;
+    }
+    if ((long long)above0 < k_rem && (long long)above0 + h0 >= k_rem) {
+        s_sel[0] = 2 * t;
+        s_sel[1] = above0;
+        s_sel[2] = h0;
+    }
+    __syncthreads();
+    if (t == 0) {
+        const unsigned prefix = st->prefix | (s_sel[0] << shift);
+        st->prefix = prefix;
+        st->pmask |= dmask << shift;
+        st->k_rem = k_rem - (long long)s_sel[1];
+        if (pass == 2) {
+            st->threshold = prefix;
+            st->need_eq = (unsigned)(k_rem - (long long)s_sel[1]);
+            st->count_eq = s_sel[2];
+        }
+    }
+}
+
+// grid (blocks_per_image, batch): histogram of digit `pass` among the keys under the prefix
+__global__ __launch_bounds__(kLB) void loss_hist_kernel(const LossArgs p, int pass)
+{
+    __shared__ unsigned s_hist[kBins];
+    const int t = threadIdx.x;
+    const int img = blockIdx.y;
+    if (p.state->k_rem <= 0) return;
+    for (int b = t; b < kBins; b += kLB) s_hist[b] = 0u;
+    __syncthreads();
+    const unsigned prefix = p.state->prefix, pmask = p.state->pmask;
+    const int shift = pass == 1 ? 10 : 0;
+    const unsigned dmask = pass == 2 ? 0x3FFu : 0x7FFu;
+    const int a0 = blockIdx.x * p.chunk;
+    const int a1 = min(a0 + p.chunk, p.num_anchors);
+    for (int a = a0 + t; a < a1; a += kLB) {
+        const unsigned key = p.key[(long long)img * p.num_anchors + a];
+        if ((key & pmask) == prefix) atomicAdd(&s_hist[(key >> shift) & dmask], 1u);
+    }
+    __syncthreads();
+    flush_hist(s_hist, p.hist + pass * kBins);
+}
+
+// grid (blocks_per_image, batch): keys equal to the threshold in this chunk
+__global__ __launch_bounds__(kLB) void loss_count_eq_kernel(const LossArgs p)
+{
+    __shared__ double s_red[kLB / 64];
+    const int t = threadIdx.x;
+    const int img = blockIdx.y;
+    const int blk = img * p.blocks_per_image + (int)blockIdx.x;
+    const LossState st = *p.state;
+    unsigned n = 0;
+    if (st.k > 0 && st.need_eq < st.count_eq) {      // otherwise every equal key is kept
+        const int a0 = blockIdx.x * p.chunk;
+        const int a1 = min(a0 + p.chunk, p.num_anchors);
+        for (int a = a0 + t; a < a1; a += kLB)
+            n += (p.key[(long long)img * p.num_anchors + a] == st.threshold) ? 1u : 0u;
+    }
+    const double tot = block_sum((double)n, s_red);
+    if (t == 0) p.chunk_eq[blk] = (unsigned)tot;
+}
+
+// One workgroup: exclusive scan of chunk_eq in place.
+__global__ __launch_bounds__(1024) void loss_scan_eq_kernel(const LossArgs p)
+{
+    __shared__ unsigned s_wtot[16];
+    __shared__ unsigned s_carry;
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int n = p.batch * p.blocks_per_image;
+    if (t == 0) s_carry = 0u;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + t;
+        const unsigned v = i < n ? p.chunk_eq[i] : 0u;
+        unsigned incl = v;
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned u = __shfl_up(incl, o);
+            if (lane >= o) incl += u;
+        }
+        if (lane == 63) s_wtot[wave] = incl;
+        __syncthreads();
+        unsigned off = s_carry;
+        for (int w = 0; w < wave; ++w) off += s_wtot[w];
+        if (i < n) p.chunk_eq[i] = off + incl - v;
+        __syncthreads();
+        if (t == 1023) s_carry = off + incl;
+        __syncthreads();
+    }
+}
+
+// grid (blocks_per_image, batch): mask, mined-negative sums, gradient
+__global__ __launch_bounds__(kLB) void loss_final_kernel(const LossArgs p)
+{
+    __shared__ double s_red[kLB / 64];
+    __shared__ unsigned s_weq[kLB / 64];
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int img = blockIdx.y;
+    const int blk = img * p.blocks_per_image + (int)blockIdx.x;
+    const LossState st = *p.state;
+    const bool any = st.k > 0;
+    const bool ordered = any && st.need_eq < st.count_eq;
+    unsigned eq_before = ordered ? p.chunk_eq[blk] : 0u;     // equal keys in earlier chunks
+    const double denom = st.n_pos > 1.0 ? st.n_pos : 1.0;     // :174
+    const float scale = (float)(1.0 / denom);
+    const int a0 = blockIdx.x * p.chunk;
+    const int a1 = min(a0 + p.chunk, p.num_anchors);
+    double neg_cls = 0.0;
+    for (int base = a0; base < a1; base += kLB) {            // tiles of consecutive anchors
+        const int a = base + t;
+        const bool in = a < a1;
+        const long long i = (long long)img * p.num_anchors + (in ? a : a1 - 1);
+        const unsigned key = p.key[i];
+        bool keep = any && in && key > st.threshold;
+        const bool eq = any && in && key == st.threshold;
+        if (ordered) {
+            // rank of this key among the equal ones, in index order
+            const u64 bal = __ballot(eq);
+            if (lane == 0) s_weq[wave] = (unsigned)__popcll(bal);
+            __syncthreads();
+            unsigned rank = eq_before + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+            unsigned tile_total = 0;
+#pragma unroll
+            for (int w = 0; w < kLB / 64; ++w) {
+                if (w < wave) rank += s_weq[w];
+                tile_total += s_weq[w];
+            }
+            keep = keep || (eq && rank < st.need_eq);
+            eq_before += tile_total;
+            __syncthreads();
+        } else {
+            keep = keep || eq;
+        }
+        if (in) {
+            const Row yt = load_row(p.y_true, i), yp = load_row(p.y_pred, i);
+            const float cls = class_loss(yt, yp);
+            neg_cls += (double)(cls * (keep ? 1.0f : 0.0f));                     // :160
+            if (p.keep) p.keep[i] = keep ? 1 : 0;
+            if (p.grad) {
+                const float pos = yt.c.y;
+                const float w = pos + (keep ? 1.0f : 0.0f);
+                float2 gc;
+                gc.x = yp.c.x >= 1e-15f ? (-(yt.c.x * w) / yp.c.x) * scale : 0.0f;
+                gc.y = yp.c.y >= 1e-15f ? (-(yt.c.y * w) / yp.c.y) * scale : 0.0f;
+                const float ap = p.alpha * pos;
+                auto dl = [](float pv, float tv) {
+                    const float d = pv - tv;
+                    return fabsf(d) < 1.0f ? d : (d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : d));
+                };
+                float2 *g = reinterpret_cast<float2 *>(p.grad + i * 6);
+                g[0] = gc;
+                g[1] = make_float2((ap * dl(yp.xy.x, yt.xy.x)) * scale, (ap * dl(yp.xy.y, yt.xy.y)) * scale);
+                g[2] = make_float2((ap * dl(yp.wh.x, yt.wh.x)) * scale, (ap * dl(yp.wh.y, yt.wh.y)) * scale);
+            }
+        }
+    }
+    neg_cls = block_sum(neg_cls, s_red);
+    if (t == 0 && neg_cls != 0.0) atomicAdd(&p.sums[4 * img + 2], neg_cls);
+}
+
+__global__ __launch_bounds__(kLB) void loss_finish_kernel(const LossArgs p)
+{
+    const int b = blockIdx.x * kLB + threadIdx.x;
+    if (b >= p.batch) return;
+    const double n_pos = p.state->n_pos;
+    const double denom = n_pos > 1.0 ? n_pos : 1.0;
+    const double *s = p.sums + 4 * b;
+    p.total[b] = (float)((s[0] + s[2] + (double)p.alpha * s[1]) / denom * (double)p.batch);   // :174-179
+}
+
+}  // namespace
+
+extern "C" int ssdbox_ssd_loss(ssdbox_ctx *ctx, const float *d_y_true, const float *d_y_pred, int batch,
+                               int64_t num_anchors, int neg_pos_ratio, int n_neg_min, float alpha,
+                               float *d_total, uint8_t *d_keep, float *d_grad)
+{
+    SSD_REQUIRE(ctx != nullptr, "ssd_loss: ctx is NULL");
+    SSD_REQUIRE(batch >= 1 && batch <= 65535, "ssd_loss: batch %d outside [1, 65535]", batch);
+    SSD_REQUIRE(num_anchors >= 1 && (long long)batch * num_anchors < (1ll << 31),
+                "ssd_loss: batch %d x %lld anchors", batch, (long long)num_anchors);
+    SSD_REQUIRE(neg_pos_ratio >= 0 && n_neg_min >= 0, "ssd_loss: negative mining parameter");
+    SSD_REQUIRE(d_y_true && d_y_pred && d_total, "ssd_loss: NULL buffer");
+
+    DeviceGuard guard(ctx->device);
+    const long long n = (long long)batch * num_anchors;
+    int bpi = (int)((num_anchors + kLB * kPerThread - 1) / (kLB * kPerThread));
+    while ((long long)bpi * batch > (1 << 20)) bpi = (bpi + 1) / 2;      // bound the chunk scan
+    long long chunk = (num_anchors + bpi - 1) / bpi;
+    chunk = (chunk + kLB - 1) / kLB * kLB;
+    bpi = (int)((num_anchors + chunk - 1) / chunk);
+
+    int rc = ensure_buffer((void **)&ctx->loss_key, &ctx->loss_key_cap, (size_t)n, sizeof(unsigned), false,
+                           ctx->stream);
+    if (rc != SSDBOX_OK) return rc;
+    // one block of small scratch: histograms, state, per-image sums, chunk counts
+    const size_t small_bytes = 3 * kBins * sizeof(unsigned) + 256 + (size_t)batch * 4 * sizeof(double) +
+                               (size_t)batch * bpi * sizeof(unsigned);
+    rc = ensure_buffer((void **)&ctx->loss_small, &ctx->loss_small_cap, small_bytes, 1, false, ctx->stream);
+    if (rc != SSDBOX_OK) return rc;
+    SSD_CHECK_HIP(hipMemsetAsync(ctx->loss_small, 0, small_bytes, ctx->stream));
+
+    LossArgs a;
+    a.y_true = d_y_true;
+    a.y_pred = d_y_pred;
+    a.batch = batch;
+    a.num_anchors = (int)num_anchors;
+    a.blocks_per_image = bpi;
+    a.chunk = (int)chunk;
+    a.neg_pos_ratio = neg_pos_ratio;
+    a.n_neg_min = n_neg_min;
+    a.alpha = alpha;
+    a.key = ctx->loss_key;
+    char *small = reinterpret_cast<char *>(ctx->loss_small);
+    a.hist = reinterpret_cast<unsigned *>(small);
+    a.state = reinterpret_cast<LossState *>(small + 3 * kBins * sizeof(unsigned));
+    a.sums = reinterpret_cast<double *>(small + 3 * kBins * sizeof(unsigned) + 256);
+    a.chunk_eq = reinterpret_cast<unsigned *>(small + 3 * kBins * sizeof(unsigned) + 256 +
+                                              (size_t)batch * 4 * sizeof(double));
+    a.total = d_total;
+    a.keep = d_keep;
+    a.grad = d_grad;
+    static_assert(sizeof(LossState) <= 256, "state block");
+
+    StageTimer timer(ctx, SSDBOX_STAGE_LOSS);
+    const dim3 grid(bpi, batch);
+    hipLaunchKernelGGL(loss_pass1_kernel, grid, dim3(kLB), 0, ctx->stream, a);
+    hipLaunchKernelGGL(loss_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, a, 0);
+    hipLaunchKernelGGL(loss_hist_kernel, grid, dim3(kLB), 0, ctx->stream, a, 1);
+    hipLaunchKernelGGL(loss_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, a, 1);
+    hipLaunchKernelGGL(loss_hist_kernel, grid, dim3(kLB), 0, ctx->stream, a, 2);
+    hipLaunchKernelGGL(loss_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, a, 2);
+    hipLaunchKernelGGL(loss_count_eq_kernel, grid, dim3(kLB), 0, ctx->stream, a);
+    hipLaunchKernelGGL(loss_scan_eq_kernel, dim3(1), dim3(1024), 0, ctx->stream, a);
+    hipLaunchKernelGGL(loss_final_kernel, grid, dim3(kLB), 0, ctx->stream, a);
+    hipLaunchKernelGGL(loss_finish_kernel, dim3((batch + kLB - 1) / kLB), dim3(kLB), 0, ctx->stream, a);
+    SSD_CHECK_HIP(hipGetLastError());
+    return SSDBOX_OK;
+}

@@ -48,7 +48,8 @@ enum {
     SSDBOX_STAGE_NMS_SCAN = 5,   /* greedy scan + detection assembly                         */
     SSDBOX_STAGE_ELEMENTWISE = 6,
     SSDBOX_STAGE_SHAPES = 7,     /* per (GT box, anchor shape) log-size table before matching */
-    SSDBOX_NUM_STAGES = 8
+    SSDBOX_STAGE_LOSS = 8,       /* SSD loss with hard-negative mining (all its launches)    */
+    SSDBOX_NUM_STAGES = 9
 };
 
 int ssdbox_version(void);
@@ -177,6 +178,17 @@ int ssdbox_prepare_gt(ssdbox_ctx *ctx, const float *d_raw_xywh, const int32_t *d
  * d_xywh (batch,limit,4) int32 and d_scores (batch,limit), zero after the count. */
 int ssdbox_widerface_rows(ssdbox_ctx *ctx, const float *d_dets, const int32_t *d_count, int batch,
                           int limit, int32_t *d_xywh, float *d_scores);
+
+/* SSD loss with hard-negative mining, utils/losses.py:97-181 (SSDLoss.call), for y_true and
+ * y_pred of shape (batch, num_anchors, 2 + 4) = [background, face, 4 offsets]:
+ * d_total (batch) the per-image loss; d_keep (batch, num_anchors) bytes, 1 where a negative was
+ * mined by the batch-wide top-k (:149-157), or NULL; d_grad (batch, num_anchors, 6) the
+ * gradient of mean(d_total) with respect to y_pred as TensorFlow's autodiff derives it (mask
+ * and counts constant), or NULL.  tf.nn.top_k's order is frozen as: larger value first, equal
+ * values by ascending flat index, NaN last. */
+int ssdbox_ssd_loss(ssdbox_ctx *ctx, const float *d_y_true, const float *d_y_pred, int batch,
+                    int64_t num_anchors, int neg_pos_ratio, int n_neg_min, float alpha,
+                    float *d_total, uint8_t *d_keep, float *d_grad);
 
 /* Device self-checks of the building blocks (wave reductions, exp/log against the values
  * in expect_log/expect_exp for the host inputs x_log/x_exp, n each).  Blocks the host.

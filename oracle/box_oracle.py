@@ -309,3 +309,80 @@ def widerface_lines(name, preds):
     for box, score in zip(boxes, scores):
         lines.append("%d %d %d %d %.3f\n" % (box[0], box[1], box[2], box[3], score))
     return "".join(lines)
+
+
+# --------------------------------------------------------------------------------------
+# SSD loss with hard-negative mining, reference utils/losses.py:41-181 (forward), and the
+# gradient TensorFlow's autodiff derives from it.  Float32 like the reference (floatx).
+# Frozen conventions: tf.nn.top_k ranks equal values by ascending index; count_nonzero treats
+# -0 as zero and NaN as nonzero; the mask and the counts carry no gradient.
+# --------------------------------------------------------------------------------------
+def smooth_l1(y_true, y_pred):
+    """utils/losses.py:58-61"""
+    diff = (y_true - y_pred).astype(F32)
+    absolute = np.abs(diff)
+    square = F32(0.5) * diff ** 2
+    return np.where(absolute < F32(1.0), square, absolute - F32(0.5)).astype(F32).sum(axis=-1, dtype=F32)
+
+
+def log_loss(y_true, y_pred, log=np.log):
+    """utils/losses.py:78-81"""
+    p = np.maximum(y_pred.astype(F32), F32(1e-15))
+    return (-(y_true.astype(F32) * log(p).astype(F32)).sum(axis=-1, dtype=F32)).astype(F32)
+
+
+def topk_indices(values, k):
+    """tf.nn.top_k(values, k).indices as a set: the k largest, equal values by ascending index
+    (NaN ranks last)."""
+    v = np.asarray(values, F32)
+    key = np.where(np.isnan(v), -np.inf, v.astype(np.float64))
+    order = np.argsort(-key, kind="stable")
+    return order[:k]
+
+
+def ssd_loss(y_true, y_pred, neg_pos_ratio=3, n_neg_min=0, alpha=1.0, log=np.log, details=False):
+    """utils/losses.py:97-181 for y_true, y_pred of shape (B, A, 2 + 4).  Returns the (B,)
+    loss; with details also (keep mask (B,A) bool, classification loss (B,A), n_positive)."""
+    yt = np.asarray(y_true, F32)
+    yp = np.asarray(y_pred, F32)
+    B, A = yp.shape[0], yp.shape[1]
+    cls = log_loss(yt[:, :, :-4], yp[:, :, :-4], log)                    # :102
+    loc = smooth_l1(yt[:, :, -4:], yp[:, :, -4:])                        # :103
+    negatives = yt[:, :, 0]                                              # :108
+    positives = yt[:, :, 1:-4].max(axis=-1)                              # :109
+    n_positive = positives.sum(dtype=np.float64)                         # :112 (exact for 0/1 labels)
+    pos_class = (cls * positives).sum(axis=-1, dtype=np.float64)         # :117
+    neg_all = (cls * negatives).astype(F32)                              # :122
+    n_neg_losses = int(np.count_nonzero(neg_all))                        # :123
+    k = min(max(int(neg_pos_ratio) * int(n_positive), int(n_neg_min)), n_neg_losses)   # :135-136
+    keep = np.zeros((B * A,), bool)
+    if n_neg_losses != 0:                                                # :163
+        keep[topk_indices(neg_all.reshape(-1), k)] = True                # :149-157
+    keep = keep.reshape(B, A)
+    neg_class = (cls * keep).sum(axis=-1, dtype=np.float64)              # :160
+    loc_sum = (loc * positives).sum(axis=-1, dtype=np.float64)           # :170
+    total = (pos_class + neg_class + float(alpha) * loc_sum) / max(1.0, float(n_positive))   # :174
+    total = (total * B).astype(F32)                                      # :179
+    if details:
+        return total, keep, cls, n_positive
+    return total
+
+
+def ssd_loss_grad(y_true, y_pred, keep, n_positive, alpha=1.0):
+    """d mean_b(loss_b) / d y_pred, what Keras back-propagates (the loss is averaged over the
+    batch after utils/losses.py:179 multiplied by it): per element
+    [-(y_true_c * w) / p_c where p_c >= 1e-15 | alpha * positives * smooth_l1'] / max(1, n_pos),
+    w = positives + keep."""
+    yt = np.asarray(y_true, F32)
+    yp = np.asarray(y_pred, F32)
+    scale = F32(1.0 / max(1.0, float(n_positive)))
+    positives = yt[:, :, 1:-4].max(axis=-1)
+    w = (positives + keep.astype(F32)).astype(F32)
+    grad = np.zeros_like(yp)
+    p = yp[:, :, :-4]
+    gp = np.where(p >= F32(1e-15), -(yt[:, :, :-4] * w[:, :, None]) / np.maximum(p, F32(1e-15)), F32(0))
+    grad[:, :, :-4] = gp * scale
+    diff = yp[:, :, -4:] - yt[:, :, -4:]
+    dl = np.where(np.abs(diff) < F32(1.0), diff, np.sign(diff)).astype(F32)
+    grad[:, :, -4:] = F32(alpha) * positives[:, :, None] * dl * scale
+    return grad.astype(F32)

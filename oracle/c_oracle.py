@@ -57,6 +57,10 @@ def lib():
         L.orc_postprocess.restype = ctypes.c_int
         L.orc_postprocess.argtypes = [c_f, c_f, ctypes.c_int64, ctypes.c_float, ctypes.c_float,
                                       ctypes.c_int, ctypes.c_float, ctypes.c_float, c_f, c_i]
+        L.orc_ssd_loss.restype = ctypes.c_int
+        L.orc_ssd_loss.argtypes = [c_f, c_f, ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
+                                   ctypes.c_float, c_f, ctypes.POINTER(ctypes.c_ubyte), c_f, c_f,
+                                   ctypes.POINTER(ctypes.c_double)]
         _lib = L
     return _lib
 
@@ -167,3 +171,24 @@ def postprocess(y_pred_image, anchors, conf_thresh, img_width=1.0, img_height=1.
                               img_width, img_height, dets.ctypes.data_as(c_f),
                               idx.ctypes.data_as(c_i))
     return dets[:k].copy(), idx[:k].copy()
+
+
+def ssd_loss(y_true, y_pred, neg_pos_ratio=3, n_neg_min=0, alpha=1.0, grad=False):
+    """(total (B,), keep (B,A) bool, cls (B,A), n_positive[, grad (B,A,6)])"""
+    yt, pt = _f(y_true)
+    yp, pp = _f(y_pred)
+    B, A = yp.shape[0], yp.shape[1]
+    assert yt.shape == yp.shape == (B, A, 6)
+    total = np.empty((B,), np.float32)
+    keep = np.empty((B, A), np.uint8)
+    cls = np.empty((B, A), np.float32)
+    g = np.empty((B, A, 6), np.float32) if grad else None
+    npos = ctypes.c_double(0.0)
+    rc = lib().orc_ssd_loss(pt, pp, B, A, int(neg_pos_ratio), int(n_neg_min), float(alpha),
+                            total.ctypes.data_as(c_f), keep.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)),
+                            cls.ctypes.data_as(c_f), g.ctypes.data_as(c_f) if grad else None,
+                            ctypes.byref(npos))
+    if rc != 0:
+        raise MemoryError("orc_ssd_loss")
+    res = (total, keep.astype(bool), cls, npos.value)
+    return res + (g,) if grad else res

@@ -338,3 +338,81 @@ int orc_postprocess(const float *y_pred, const float *anchors, int64_t A, float 
     free(cb); free(cs); free(ca); free(keep);
     return nk;
 }
+
+/* ------------------------------------------------------------------------------- loss */
+/* SSD loss with hard-negative mining, utils/losses.py:97-181, for rows of 2 + 4 values
+ * [background, face, 4 offsets], and the gradient of its batch mean with respect to y_pred
+ * (what TensorFlow's autodiff gives: the mask and the counts are constants).
+ * Per-anchor values are float32 (logarithm = orc_logf), sums run in double.
+ * keep (B*A) receives the mined-negative mask; cls and grad may be NULL.
+ * tf.nn.top_k order: larger value first, equal values by ascending index, NaN last. */
+int orc_ssd_loss(const float *yt, const float *yp, int B, int64_t A, int neg_pos_ratio,
+                 int n_neg_min, float alpha, float *total, unsigned char *keep, float *cls_out,
+                 float *grad, double *n_positive_out)
+{
+    const int64_t N = (int64_t)B * A;
+    float *cls = (float *)malloc(sizeof(float) * (size_t)N);
+    float *loc = (float *)malloc(sizeof(float) * (size_t)N);
+    ranked_t *r = (ranked_t *)malloc(sizeof(ranked_t) * (size_t)N);
+    if (!cls || !loc || !r || N >= (1ll << 31)) { free(cls); free(loc); free(r); return -1; }
+    double n_pos = 0.0;
+    int64_t n_neg_losses = 0;
+    for (int64_t i = 0; i < N; ++i) {
+        const float *t = yt + 6 * i, *p = yp + 6 * i;
+        const float l0 = orc_logf(fmaxf(p[0], 1e-15f)), l1 = orc_logf(fmaxf(p[1], 1e-15f));
+        cls[i] = -(t[0] * l0 + t[1] * l1);                      /* :78-81 */
+        float s = 0.0f;
+        for (int c = 0; c < 4; ++c) {                           /* :58-61 */
+            const float d = t[2 + c] - p[2 + c];
+            const float a = fabsf(d);
+            s = s + (a < 1.0f ? 0.5f * (d * d) : a - 0.5f);
+        }
+        loc[i] = s;
+        n_pos += (double)t[1];                                  /* :109-112 */
+        const float neg_all = cls[i] * t[0];                    /* :122 */
+        if (neg_all != 0.0f) ++n_neg_losses;                    /* :123, NaN counts */
+        r[i].score = neg_all;
+        r[i].idx = (int32_t)i;
+        keep[i] = 0;
+    }
+    int64_t k = (int64_t)neg_pos_ratio * (int64_t)n_pos;        /* :135-136 */
+    if (k < n_neg_min) k = n_neg_min;
+    if (k > n_neg_losses) k = n_neg_losses;
+    if (n_neg_losses != 0 && k > 0) {                           /* :163, :149-157 */
+        qsort(r, (size_t)N, sizeof(ranked_t), rank_cmp);
+        for (int64_t i = 0; i < k; ++i) keep[r[i].idx] = 1;
+    }
+    const double denom = n_pos > 1.0 ? n_pos : 1.0;             /* :174 */
+    for (int b = 0; b < B; ++b) {
+        double pos_c = 0.0, neg_c = 0.0, loc_s = 0.0;
+        for (int64_t a = 0; a < A; ++a) {
+            const int64_t i = (int64_t)b * A + a;
+            const float pos = yt[6 * i + 1];
+            pos_c += (double)(cls[i] * pos);                    /* :117 */
+            neg_c += (double)(cls[i] * (float)keep[i]);         /* :160 */
+            loc_s += (double)(loc[i] * pos);                    /* :170 */
+        }
+        total[b] = (float)((pos_c + neg_c + (double)alpha * loc_s) / denom * (double)B);   /* :174-179 */
+    }
+    if (grad) {
+        const float scale = (float)(1.0 / denom);
+        for (int64_t i = 0; i < N; ++i) {
+            const float *t = yt + 6 * i, *p = yp + 6 * i;
+            float *g = grad + 6 * i;
+            const float w = t[1] + (float)keep[i];
+            for (int c = 0; c < 2; ++c)
+                g[c] = p[c] >= 1e-15f ? (-(t[c] * w) / p[c]) * scale : 0.0f;
+            for (int c = 0; c < 4; ++c) {
+                const float d = p[2 + c] - t[2 + c];
+                const float dl = fabsf(d) < 1.0f ? d : (d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : d));
+                g[2 + c] = ((alpha * t[1]) * dl) * scale;
+            }
+        }
+    }
+    if (cls_out) memcpy(cls_out, cls, sizeof(float) * (size_t)N);
+    if (n_positive_out) *n_positive_out = n_pos;
+    free(cls);
+    free(loc);
+    free(r);
+    return 0;
+}

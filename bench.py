@@ -365,6 +365,10 @@ def main():
         for i in range(args.warmup + args.steps):
             wl.step(i)
         torch.cuda.synchronize()
+        wl.setup_loss()
+        for _ in range(10):
+            wl.loss(wl.slots[0])
+        torch.cuda.synchronize()
         return
 
     elapsed = timed_loop(torch, dist, world, wl.step, args.steps, args.warmup)

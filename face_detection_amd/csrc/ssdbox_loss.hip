@@ -71,6 +71,20 @@ SSD_DEV Row load_row(const float *base, long long i)
     return r;
 }
 
+// Two consecutive rows (48 bytes, 16-byte aligned when the first index is even and rows per
+// image are even) as three 16-byte loads.
+SSD_DEV void load_row_pair(const float *base, long long i, Row &a, Row &b)
+{
+    const float4 *p = reinterpret_cast<const float4 *>(base + i * 6);
+    const float4 v0 = p[0], v1 = p[1], v2 = p[2];
+    a.c = make_float2(v0.x, v0.y);
+    a.xy = make_float2(v0.z, v0.w);
+    a.wh = make_float2(v1.x, v1.y);
+    b.c = make_float2(v1.z, v1.w);
+    b.xy = make_float2(v2.x, v2.y);
+    b.wh = make_float2(v2.z, v2.w);
+}
+
 // utils/losses.py:78-81
 SSD_DEV float class_loss(const Row &t, const Row &p)
 {
@@ -116,9 +130,11 @@ SSD_DEV void flush_hist(const unsigned *s_hist, unsigned *g_hist)
     }
 }
 
-// grid (blocks_per_image, batch)
+// grid (blocks_per_image, batch); PAIR: a thread takes two consecutive anchors at a time
+template <bool PAIR>
 __global__ __launch_bounds__(kLB) void loss_pass1_kernel(const LossArgs p)
 {
+    constexpr int E = PAIR ? 2 : 1;
     __shared__ unsigned s_hist[kBins];
     __shared__ double s_red[kLB / 64];
     const int t = threadIdx.x;
@@ -129,20 +145,34 @@ __global__ __launch_bounds__(kLB) void loss_pass1_kernel(const LossArgs p)
     const int a1 = min(a0 + p.chunk, p.num_anchors);
     double pos_cls = 0.0, loc_s = 0.0, n_pos = 0.0;
     unsigned nonzero = 0;
-    for (int a = a0 + t; a < a1; a += kLB) {
+    for (int a = a0 + E * t; a < a1; a += E * kLB) {
         const long long i = (long long)img * p.num_anchors + a;
-        const Row yt = load_row(p.y_true, i), yp = load_row(p.y_pred, i);
-        const float cls = class_loss(yt, yp);
-        const float loc = loc_loss(yt, yp);
-        const float pos = yt.c.y;                          // :109 (one class besides background)
-        pos_cls += (double)(cls * pos);                    // :117
-        loc_s += (double)(loc * pos);                      // :170
-        n_pos += (double)pos;                              // :112
-        const float neg_all = cls * yt.c.x;                // :122
-        nonzero += (neg_all != 0.0f) ? 1u : 0u;            // :123 (NaN counts, -0 does not)
-        const unsigned key = score_key(neg_all);
-        p.key[i] = key;
-        atomicAdd(&s_hist[key >> 21], 1u);
+        Row yt[E], yp[E];
+        if (PAIR) {
+            load_row_pair(p.y_true, i, yt[0], yt[E - 1]);
+            load_row_pair(p.y_pred, i, yp[0], yp[E - 1]);
+        } else {
+            yt[0] = load_row(p.y_true, i);
+            yp[0] = load_row(p.y_pred, i);
+        }
+        unsigned key[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const float cls = class_loss(yt[e], yp[e]);
+            const float loc = loc_loss(yt[e], yp[e]);
+            const float pos = yt[e].c.y;                   // :109 (one class besides background)
+            pos_cls += (double)(cls * pos);                // :117
+            loc_s += (double)(loc * pos);                  // :170
+            n_pos += (double)pos;                          // :112
+            const float neg_all = cls * yt[e].c.x;         // :122
+            nonzero += (neg_all != 0.0f) ? 1u : 0u;        // :123 (NaN counts, -0 does not)
+            key[e] = score_key(neg_all);
+            atomicAdd(&s_hist[key[e] >> 21], 1u);
+        }
+        if (PAIR)
+            *reinterpret_cast<uint2 *>(p.key + i) = make_uint2(key[0], key[E - 1]);
+        else
+            p.key[i] = key[0];
     }
     pos_cls = block_sum(pos_cls, s_red);
     loc_s = block_sum(loc_s, s_red);
@@ -299,9 +329,17 @@ __global__ __launch_bounds__(1024) void loss_scan_eq_kernel(const LossArgs p)
     }
 }
 
+SSD_DEV float smooth_l1_slope(float pv, float tv)
+{
+    const float d = pv - tv;
+    return fabsf(d) < 1.0f ? d : (d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : d));
+}
+
 // grid (blocks_per_image, batch): mask, mined-negative sums, gradient
+template <bool PAIR>
 __global__ __launch_bounds__(kLB) void loss_final_kernel(const LossArgs p)
 {
+    constexpr int E = PAIR ? 2 : 1;
     __shared__ double s_red[kLB / 64];
     __shared__ unsigned s_weq[kLB / 64];
     const int t = threadIdx.x;
@@ -317,51 +355,99 @@ __global__ __launch_bounds__(kLB) void loss_final_kernel(const LossArgs p)
     const int a0 = blockIdx.x * p.chunk;
     const int a1 = min(a0 + p.chunk, p.num_anchors);
     double neg_cls = 0.0;
-    for (int base = a0; base < a1; base += kLB) {            // tiles of consecutive anchors
-        const int a = base + t;
-        const bool in = a < a1;
-        const long long i = (long long)img * p.num_anchors + (in ? a : a1 - 1);
-        const unsigned key = p.key[i];
-        bool keep = any && in && key > st.threshold;
-        const bool eq = any && in && key == st.threshold;
+    for (int base = a0; base < a1; base += E * kLB) {        // tiles of consecutive anchors
+        const int a = base + E * t;
+        const bool in = a < a1;                              // PAIR: a1 - a0 is even
+        const long long i = (long long)img * p.num_anchors + (in ? a : a1 - E);
+        unsigned key[E];
+        if (PAIR) {
+            const uint2 kk = *reinterpret_cast<const uint2 *>(p.key + i);
+            key[0] = kk.x;
+            key[E - 1] = kk.y;
+        } else {
+            key[0] = p.key[i];
+        }
+        bool keep[E], eq[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            keep[e] = any && in && key[e] > st.threshold;
+            eq[e] = any && in && key[e] == st.threshold;
+        }
         if (ordered) {
-            // rank of this key among the equal ones, in index order
-            const u64 bal = __ballot(eq);
-            if (lane == 0) s_weq[wave] = (unsigned)__popcll(bal);
+            // rank of each key among the equal ones, in index order
+            u64 bal[E];
+            unsigned mine = 0;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                bal[e] = __ballot(eq[e]);
+                mine += (unsigned)__popcll(bal[e]);
+            }
+            if (lane == 0) s_weq[wave] = mine;
             __syncthreads();
-            unsigned rank = eq_before + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+            unsigned rank = eq_before;
+#pragma unroll
+            for (int e = 0; e < E; ++e) rank += (unsigned)__popcll(bal[e] & ((1ull << lane) - 1ull));
             unsigned tile_total = 0;
 #pragma unroll
             for (int w = 0; w < kLB / 64; ++w) {
                 if (w < wave) rank += s_weq[w];
                 tile_total += s_weq[w];
             }
-            keep = keep || (eq && rank < st.need_eq);
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                keep[e] = keep[e] || (eq[e] && rank < st.need_eq);
+                rank += eq[e] ? 1u : 0u;
+            }
             eq_before += tile_total;
             __syncthreads();
         } else {
-            keep = keep || eq;
+#pragma unroll
+            for (int e = 0; e < E; ++e) keep[e] = keep[e] || eq[e];
         }
         if (in) {
-            const Row yt = load_row(p.y_true, i), yp = load_row(p.y_pred, i);
-            const float cls = class_loss(yt, yp);
-            neg_cls += (double)(cls * (keep ? 1.0f : 0.0f));                     // :160
-            if (p.keep) p.keep[i] = keep ? 1 : 0;
-            if (p.grad) {
-                const float pos = yt.c.y;
-                const float w = pos + (keep ? 1.0f : 0.0f);
-                float2 gc;
-                gc.x = yp.c.x >= 1e-15f ? (-(yt.c.x * w) / yp.c.x) * scale : 0.0f;
-                gc.y = yp.c.y >= 1e-15f ? (-(yt.c.y * w) / yp.c.y) * scale : 0.0f;
+            Row yt[E], yp[E];
+            if (PAIR) {
+                load_row_pair(p.y_true, i, yt[0], yt[E - 1]);
+                load_row_pair(p.y_pred, i, yp[0], yp[E - 1]);
+            } else {
+                yt[0] = load_row(p.y_true, i);
+                yp[0] = load_row(p.y_pred, i);
+            }
+            float g[E][6];
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const float cls = class_loss(yt[e], yp[e]);
+                const float kf = keep[e] ? 1.0f : 0.0f;
+                neg_cls += (double)(cls * kf);                                    // :160
+                const float pos = yt[e].c.y;
+                const float w = pos + kf;
+                g[e][0] = yp[e].c.x >= 1e-15f ? (-(yt[e].c.x * w) / yp[e].c.x) * scale : 0.0f;
+                g[e][1] = yp[e].c.y >= 1e-15f ? (-(yt[e].c.y * w) / yp[e].c.y) * scale : 0.0f;
                 const float ap = p.alpha * pos;
-                auto dl = [](float pv, float tv) {
-                    const float d = pv - tv;
-                    return fabsf(d) < 1.0f ? d : (d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : d));
-                };
-                float2 *g = reinterpret_cast<float2 *>(p.grad + i * 6);
-                g[0] = gc;
-                g[1] = make_float2((ap * dl(yp.xy.x, yt.xy.x)) * scale, (ap * dl(yp.xy.y, yt.xy.y)) * scale);
-                g[2] = make_float2((ap * dl(yp.wh.x, yt.wh.x)) * scale, (ap * dl(yp.wh.y, yt.wh.y)) * scale);
+                g[e][2] = (ap * smooth_l1_slope(yp[e].xy.x, yt[e].xy.x)) * scale;
+                g[e][3] = (ap * smooth_l1_slope(yp[e].xy.y, yt[e].xy.y)) * scale;
+                g[e][4] = (ap * smooth_l1_slope(yp[e].wh.x, yt[e].wh.x)) * scale;
+                g[e][5] = (ap * smooth_l1_slope(yp[e].wh.y, yt[e].wh.y)) * scale;
+            }
+            if (p.keep) {
+                if (PAIR)
+                    *reinterpret_cast<unsigned short *>(p.keep + i) =
+                        (unsigned short)((keep[0] ? 1u : 0u) | (keep[E - 1] ? 0x100u : 0u));
+                else
+                    p.keep[i] = keep[0] ? 1 : 0;
+            }
+            if (p.grad) {
+                if (PAIR) {
+                    float4 *o = reinterpret_cast<float4 *>(p.grad + i * 6);
+                    o[0] = make_float4(g[0][0], g[0][1], g[0][2], g[0][3]);
+                    o[1] = make_float4(g[0][4], g[0][5], g[E - 1][0], g[E - 1][1]);
+                    o[2] = make_float4(g[E - 1][2], g[E - 1][3], g[E - 1][4], g[E - 1][5]);
+                } else {
+                    float2 *o = reinterpret_cast<float2 *>(p.grad + i * 6);
+                    o[0] = make_float2(g[0][0], g[0][1]);
+                    o[1] = make_float2(g[0][2], g[0][3]);
+                    o[2] = make_float2(g[0][4], g[0][5]);
+                }
             }
         }
     }
@@ -434,7 +520,14 @@ extern "C" int ssdbox_ssd_loss(ssdbox_ctx *ctx, const float *d_y_true, const flo
 
     StageTimer timer(ctx, SSDBOX_STAGE_LOSS);
     const dim3 grid(bpi, batch);
-    hipLaunchKernelGGL(loss_pass1_kernel, grid, dim3(kLB), 0, ctx->stream, a);
+    // two anchors per thread and load where every pair is 16-byte aligned
+    const bool pair = num_anchors % 2 == 0 && ((uintptr_t)d_y_true % 16) == 0 && ((uintptr_t)d_y_pred % 16) == 0 &&
+                      (d_grad == nullptr || ((uintptr_t)d_grad % 16) == 0) &&
+                      (d_keep == nullptr || ((uintptr_t)d_keep % 2) == 0);
+    if (pair)
+        hipLaunchKernelGGL(loss_pass1_kernel<true>, grid, dim3(kLB), 0, ctx->stream, a);
+    else
+        hipLaunchKernelGGL(loss_pass1_kernel<false>, grid, dim3(kLB), 0, ctx->stream, a);
     hipLaunchKernelGGL(loss_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, a, 0);
     hipLaunchKernelGGL(loss_hist_kernel, grid, dim3(kLB), 0, ctx->stream, a, 1);
     hipLaunchKernelGGL(loss_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, a, 1);
@@ -442,7 +535,10 @@ extern "C" int ssdbox_ssd_loss(ssdbox_ctx *ctx, const float *d_y_true, const flo
     hipLaunchKernelGGL(loss_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, a, 2);
     hipLaunchKernelGGL(loss_count_eq_kernel, grid, dim3(kLB), 0, ctx->stream, a);
     hipLaunchKernelGGL(loss_scan_eq_kernel, dim3(1), dim3(1024), 0, ctx->stream, a);
-    hipLaunchKernelGGL(loss_final_kernel, grid, dim3(kLB), 0, ctx->stream, a);
+    if (pair)
+        hipLaunchKernelGGL(loss_final_kernel<true>, grid, dim3(kLB), 0, ctx->stream, a);
+    else
+        hipLaunchKernelGGL(loss_final_kernel<false>, grid, dim3(kLB), 0, ctx->stream, a);
     hipLaunchKernelGGL(loss_finish_kernel, dim3((batch + kLB - 1) / kLB), dim3(kLB), 0, ctx->stream, a);
     SSD_CHECK_HIP(hipGetLastError());
     return SSDBOX_OK;

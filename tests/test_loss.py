@@ -111,7 +111,8 @@ def test_c_oracle_matches_numpy(seed, B, A, kw):
 @pytest.mark.parametrize("seed,B,A,kw,ties", [
     (0, 3, 500, {}, False), (1, 2, 3000, {"neg_pos_ratio": 1}, False),
     (2, 4, 777, {"n_neg_min": 50, "alpha": 0.5}, True), (3, 1, 64, {}, True),
-    (4, 5, 2049, {"neg_pos_ratio": 7}, True), (5, 2, 300, {"neg_pos_ratio": 0}, False)])
+    (4, 5, 2049, {"neg_pos_ratio": 7}, True), (5, 2, 300, {"neg_pos_ratio": 0}, False),
+    (6, 3, 6002, {"neg_pos_ratio": 2}, True)])
 def test_hip_loss_matches_c_oracle(seed, B, A, kw, ties):
     import face_detection_amd as fda
     rng = np.random.default_rng(seed)

@@ -323,6 +323,23 @@ def pcie_times(wl, reps=5):
     return {"h2d_ms": h2d * 1e3, "d2h_ms": d2h * 1e3, "h2d_bytes": nbytes_in, "d2h_bytes": nbytes_out}
 
 
+def hbm_copy_rate(torch, nbytes=1 << 28, reps=20):
+    """Achievable HBM bandwidth on this box: device-to-device copy of 256 MiB, read + write
+    bytes per second (the roofline fractions are quoted against the nominal peak instead)."""
+    src = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    dst = torch.empty_like(src)
+    src.zero_()
+    for _ in range(3):
+        dst.copy_(src)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def single_batch_latency(wl, reps=30):
     """Wall time of one step on one stream with nothing else in flight."""
     torch = wl.torch
@@ -380,6 +397,14 @@ def main():
     t_match = timed_loop(torch, dist, world, lambda i: wl.match(wl.slots[i % nslots]), args.steps, 5)
     t_det = timed_loop(torch, dist, world, lambda i: wl.detect(wl.slots[i % nslots]), args.steps, 5)
 
+    # evaluation.py:67 runs the same post-processing with threshold 0: every anchor is a candidate
+    thr = args.score_thr
+    args.score_thr = 0.0
+    n_det0 = max(args.steps // 4, 10)
+    t_det0 = timed_loop(torch, dist, world, lambda i: wl.detect(wl.slots[i % nslots]), n_det0, 3)
+    stages0 = stage_times(wl, 20) if rank == 0 else {}
+    args.score_thr = thr
+
     # the training-side consumer of the targets: SSD loss with hard-negative mining, value and
     # gradient (not part of `value`)
     wl.setup_loss()
@@ -433,6 +458,10 @@ def main():
             },
             "match_encode_images_per_s": args.batch * args.steps * world / t_match,
             "decode_nms_images_per_s": args.batch * args.steps * world / t_det,
+            "decode_nms_thr0_images_per_s": args.batch * n_det0 * world / t_det0,
+            "kernel_us_thr0": {k: round(v, 2) for k, v in stages0.items()
+                               if k in ("select", "topk", "nms_mask", "nms_scan")},
+            "hbm_copy_GBs": hbm_copy_rate(torch),
             "ssd_loss_fwd_bwd_images_per_s": args.batch * n_loss * world / t_loss,
             "ssd_loss_fwd_bwd_ms": t_loss / n_loss * 1e3,
             "kernel_us": {k: round(v, 2) for k, v in stages.items()},

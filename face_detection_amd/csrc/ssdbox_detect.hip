@@ -216,6 +216,33 @@ struct SortStep {
     }
 };
 
+// Calls f(key) for every candidate key of an image still in global memory.  A wave takes
+// four segments at a time: sixteen 512-byte loads in flight per wave, addresses clamped into
+// the segment so that no load depends on a count.
+template <typename F>
+SSD_DEV void for_each_candidate(const u64 *__restrict__ cand, const int *__restrict__ segc, int nseg,
+                                int wave, int lane, F f)
+{
+    constexpr int kWaves = kTopkBlock / 64;
+    for (int s0 = wave * 4; s0 < nseg; s0 += kWaves * 4) {
+        int cnt[4];
+        u64 key[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) cnt[u] = (s0 + u < nseg) ? segc[s0 + u] : 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const u64 *src = cand + (long long)min(s0 + u, nseg - 1) * kSeg;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) key[u][q] = src[min(q * 64 + lane, max(cnt[u] - 1, 0))];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (q * 64 + lane < cnt[u]) f(key[u][q]);
+    }
+}
+
 __global__ __launch_bounds__(kTopkBlock) void topk_sort_kernel(const TopkArgs p)
 {
     __shared__ u64 s_keys[kCap];
@@ -295,13 +322,10 @@ __global__ __launch_bounds__(kTopkBlock) void topk_sort_kernel(const TopkArgs p)
                 }
                 if (t == 0) s_count = n;
             } else {
-                for (int s = t; s < nseg * kSeg; s += kTopkBlock) {
-                    if ((s & (kSeg - 1)) < segc[s >> 8]) {
-                        const u64 key = cand[s];
-                        if (above_bucket(bk, key, lo, scale) || in_bucket(bk, key, lo, scale))
-                            s_keys[atomicAdd(&s_count, 1)] = key;
-                    }
-                }
+                for_each_candidate(cand, segc, nseg, wave, lane, [&](u64 key) {
+                    if (above_bucket(bk, key, lo, scale) || in_bucket(bk, key, lo, scale))
+                        s_keys[atomicAdd(&s_count, 1)] = key;
+                });
             }
             __syncthreads();
             m_lds = s_count;           // == n_above + bucket
@@ -324,14 +348,11 @@ __global__ __launch_bounds__(kTopkBlock) void topk_sort_kernel(const TopkArgs p)
                                              : (int)((unsigned int)(key >> shift) & dmask)], 1u);
             }
         } else {
-            for (int s = t; s < nseg * kSeg; s += kTopkBlock) {
-                if ((s & (kSeg - 1)) < segc[s >> 8]) {
-                    const u64 key = cand[s];
-                    if (in_bucket(bk, key, lo, scale))
-                        atomicAdd(&s_hist[dg < 0 ? linear_bin(key, lo, scale)
-                                                 : (int)((unsigned int)(key >> shift) & dmask)], 1u);
-                }
-            }
+            for_each_candidate(cand, segc, nseg, wave, lane, [&](u64 key) {
+                if (in_bucket(bk, key, lo, scale))
+                    atomicAdd(&s_hist[dg < 0 ? linear_bin(key, lo, scale)
+                                             : (int)((unsigned int)(key >> shift) & dmask)], 1u);
+            });
         }
         __syncthreads();
         // ---- the digit where the count from the top crosses k_rem

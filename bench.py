@@ -39,7 +39,7 @@ def parse_args():
     ap.add_argument("--ratios", default="config", choices=["config", "model"])
     ap.add_argument("--score-thr", type=float, default=0.05)
     ap.add_argument("--stress", action="store_true", help="256 ground-truth boxes in every image")
-    ap.add_argument("--streams", type=int, default=8, help="batches in flight (one stream and context each)")
+    ap.add_argument("--streams", type=int, default=16, help="batches in flight (one stream and context each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=24)
     ap.add_argument("--anchors", default="geometry", choices=["geometry", "array"],

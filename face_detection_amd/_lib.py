@@ -51,6 +51,7 @@ SIGNATURES = {
     "ssdbox_match_encode": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp, _vp]),
     "ssdbox_match_encode_ytrue": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i, _i, _f, _f, _vp]),
     "ssdbox_decode_nms": (_i, [_vp, _vp, _vp, _i64, _vp, _i, _f, _f, _i, _vp, _vp, _vp, _vp]),
+    "ssdbox_decode_nms_logits": (_i, [_vp, _vp, _vp, _i64, _vp, _i, _f, _f, _i, _vp, _vp, _vp, _vp]),
     "ssdbox_compute_nms": (_i, [_vp, _vp, _vp, _i64, _f, _i, _vp, _vp]),
     "ssdbox_compute_area": (_i, [_vp, _vp, _vp, _i64, _f, _vp]),
     "ssdbox_compute_iou": (_i, [_vp, _vp, _i64, _vp, _i64, _f, _vp]),

@@ -78,10 +78,12 @@ def match_encode_batch(anchors, gt_boxes, gt_count, gt_labels=None, max_size=512
 
 
 def decode_nms_batch(anchors, y_pred, score_threshold, nms_threshold=0.45, limit=1000,
-                     img_wh=None, context=None):
+                     img_wh=None, context=None, from_logits=False):
     """Detections for a batch of head outputs.
 
-    y_pred (B,A,6) = [softmax_bg, softmax_face, tx, ty, tw, th]; img_wh (B,2) original
+    y_pred (B,A,6) = [softmax_bg, softmax_face, tx, ty, tw, th], or with from_logits=True the
+    two class columns before the softmax of reference models/ssd.py:95 (the scores are then
+    the float32 two-class softmax of those columns); img_wh (B,2) original
     (width, height) per image or None for normalised output.  Returns
     (dets (B,limit,6) rows [1, score, xmin, ymin, xmax, ymax] in kept order and zero
     after the count, keep_idx (B,limit) int32 anchor indices (-1 after the count),
@@ -108,7 +110,8 @@ def decode_nms_batch(anchors, y_pred, score_threshold, nms_threshold=0.45, limit
     count = torch.empty((B,), dtype=torch.int32, device=y.device)
     if B == 0:
         return from_device(dets, family), from_device(keep, family), from_device(count, family)
-    _lib.check(ctx.lib.ssdbox_decode_nms(
+    fn = ctx.lib.ssdbox_decode_nms_logits if from_logits else ctx.lib.ssdbox_decode_nms
+    _lib.check(fn(
         ctx.handle, geom, _ptr(anc), A, _ptr(y), B, float(score_threshold), float(nms_threshold),
         limit, _ptr(wh), _ptr(dets), _ptr(keep), _ptr(count)))
     return from_device(dets, family), from_device(keep, family), from_device(count, family)

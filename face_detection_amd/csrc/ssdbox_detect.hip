@@ -38,9 +38,20 @@ constexpr int kTopkBlock = 1024;
 constexpr float kNmsMaxSize = 512.0f;      // compute_iou's default inside compute_nms (:205)
 
 // ------------------------------------------------------------------------------ select
+// Face probability of a two-class softmax over raw head logits (reference models/ssd.py:95;
+// the commented-out tf.math.softmax of inference.py:40): exp of the shifted logits times the
+// reciprocal of their sum, every step rounded to float32.
+SSD_DEV float softmax_face(float l0, float l1)
+{
+    const float m = fmaxf(l0, l1);
+    const float e0 = ssd_expf(l0 - m), e1 = ssd_expf(l1 - m);
+    return e1 * (1.0f / (e0 + e1));
+}
+
 // Head rows are 24 bytes [bg, face, tx, ty, tw, th]; read as a float4 stream, the face score
 // of anchor 2q sits in .y of float4 3q and that of anchor 2q+1 in .w of float4 3q+1.  A wave
 // owns 384 consecutive float4 (256 anchors): six fully coalesced 1-KiB loads.
+template <bool LOGITS>
 __global__ __launch_bounds__(kSelBlock) void select_rows6_kernel(const float4 *__restrict__ y, int n,
                                                                  float thr, u64 *__restrict__ cand,
                                                                  int *__restrict__ seg_count, int nseg)
@@ -66,7 +77,8 @@ __global__ __launch_bounds__(kSelBlock) void select_rows6_kernel(const float4 *_
         const unsigned f = f0 + 64u * k;
         const unsigned q = __umulhi(f, 0xAAAAAAABu) >> 1;      // f / 3
         const unsigned r = f - 3u * q;
-        const float score = (r == 0u) ? v[k].y : v[k].w;
+        const float s1 = (r == 0u) ? v[k].y : v[k].w;
+        const float score = LOGITS ? softmax_face((r == 0u) ? v[k].x : v[k].z, s1) : s1;
         const bool pass = (f < nf) && (r != 2u) && (score > thr);   // strict >, NaN fails
         const u64 bal = __ballot(pass);
         if (pass) out[off + __popcll(bal & lt)] = rank_key(score, 2u * q + r);
@@ -79,7 +91,7 @@ __global__ __launch_bounds__(kSelBlock) void select_rows6_kernel(const float4 *_
 // score arrays and for head outputs whose rows are not 16-byte aligned (odd anchor count).
 __global__ __launch_bounds__(kSelBlock) void select_strided_kernel(
     const float *__restrict__ scores, long long img_stride, int elem_stride, int elem_off, int n,
-    float thr, int use_thr, u64 *__restrict__ cand, int *__restrict__ seg_count, int nseg)
+    float thr, int use_thr, int logits, u64 *__restrict__ cand, int *__restrict__ seg_count, int nseg)
 {
     const int lane = threadIdx.x & 63;
     const int seg = blockIdx.x * (kSelBlock / 64) + (threadIdx.x >> 6);
@@ -91,6 +103,8 @@ __global__ __launch_bounds__(kSelBlock) void select_strided_kernel(
     for (int k = 0; k < 4; ++k) {
         const int i = seg * kSeg + k * 64 + lane;
         s[k] = (i < n) ? sc[(long long)i * elem_stride + elem_off] : 0.0f;
+        // the background logit sits right before the face logit
+        if (logits) s[k] = softmax_face((i < n) ? sc[(long long)i * elem_stride + elem_off - 1] : 0.0f, s[k]);
     }
     u64 *out = cand + ((long long)img * nseg + seg) * kSeg;
     const u64 lt = (1ull << lane) - 1ull;
@@ -116,6 +130,7 @@ struct BoxSource {
     const float *y_pred;          // (batch, n, 6)
     const float4 *boxes;          // (n, 4), mode 2
     const float *scores;          // (n), mode 2
+    int logits;                   // y_pred columns 0 and 1 are raw logits
 };
 
 struct TopkArgs {
@@ -440,7 +455,7 @@ __global__ __launch_bounds__(kTopkBlock) void topk_sort_kernel(const TopkArgs p)
             score = p.src.scores[idx];
         } else {
             const float *row = p.src.y_pred + ((long long)img * p.n_per_image + idx) * 6;
-            score = row[1];
+            score = p.src.logits ? softmax_face(row[0], row[1]) : row[1];
             const float2 lxy = *reinterpret_cast<const float2 *>(row + 2);
             const float2 lwh = *reinterpret_cast<const float2 *>(row + 4);
             const float4 anc = (p.src.mode == 0)
@@ -713,6 +728,7 @@ struct ScoreLayout {
     int use_thr;
     float thr;
     bool rows6;                    // (batch, n, 6) head rows, 16-byte aligned per image
+    bool logits;                   // scores are the softmax of elements elem_off - 1 and elem_off
 };
 
 int run_detect(ssdbox_ctx *ctx, const ScoreLayout &sl, long long n, int batch, float nms_thr,
@@ -725,14 +741,18 @@ int run_detect(ssdbox_ctx *ctx, const ScoreLayout &sl, long long n, int batch, f
     {
         StageTimer timer(ctx, SSDBOX_STAGE_SELECT);
         dim3 grid((unsigned)((nseg + kSelBlock / 64 - 1) / (kSelBlock / 64)), batch);
-        if (sl.rows6) {
-            hipLaunchKernelGGL(select_rows6_kernel, grid, dim3(kSelBlock), 0, ctx->stream,
+        if (sl.rows6 && sl.logits) {
+            hipLaunchKernelGGL(select_rows6_kernel<true>, grid, dim3(kSelBlock), 0, ctx->stream,
+                               reinterpret_cast<const float4 *>(sl.scores), (int)n, sl.thr, ctx->cand,
+                               ctx->cand_count, nseg);
+        } else if (sl.rows6) {
+            hipLaunchKernelGGL(select_rows6_kernel<false>, grid, dim3(kSelBlock), 0, ctx->stream,
                                reinterpret_cast<const float4 *>(sl.scores), (int)n, sl.thr, ctx->cand,
                                ctx->cand_count, nseg);
         } else {
             hipLaunchKernelGGL(select_strided_kernel, grid, dim3(kSelBlock), 0, ctx->stream,
                                sl.scores, sl.img_stride, sl.elem_stride, sl.elem_off, (int)n, sl.thr,
-                               sl.use_thr, ctx->cand, ctx->cand_count, nseg);
+                               sl.use_thr, sl.logits ? 1 : 0, ctx->cand, ctx->cand_count, nseg);
         }
     }
     SSD_CHECK_HIP(hipGetLastError());
@@ -777,11 +797,11 @@ int run_detect(ssdbox_ctx *ctx, const ScoreLayout &sl, long long n, int batch, f
 
 }  // namespace
 
-extern "C" int ssdbox_decode_nms(ssdbox_ctx *ctx, const ssdbox_geom *geom, const float *d_anchors,
-                                 int64_t num_anchors, const float *d_y_pred, int batch,
-                                 float score_threshold, float nms_threshold, int limit,
-                                 const float *d_img_wh, float *d_dets, int32_t *d_keep_idx,
-                                 int32_t *d_count)
+static int decode_nms_common(ssdbox_ctx *ctx, const ssdbox_geom *geom, const float *d_anchors,
+                             int64_t num_anchors, const float *d_y_pred, int batch,
+                             float score_threshold, float nms_threshold, int limit,
+                             const float *d_img_wh, float *d_dets, int32_t *d_keep_idx,
+                             int32_t *d_count, bool logits)
 {
     SSD_REQUIRE(ctx != nullptr, "decode_nms: ctx is NULL");
     SSD_REQUIRE((geom != nullptr) != (d_anchors != nullptr),
@@ -816,7 +836,9 @@ extern "C" int ssdbox_decode_nms(ssdbox_ctx *ctx, const ssdbox_geom *geom, const
     src.y_pred = d_y_pred;
     src.boxes = nullptr;
     src.scores = nullptr;
+    src.logits = logits ? 1 : 0;
     ScoreLayout sl;
+    sl.logits = logits;
     sl.scores = d_y_pred;
     sl.img_stride = (long long)num_anchors * 6;
     sl.elem_stride = 6;
@@ -827,6 +849,26 @@ extern "C" int ssdbox_decode_nms(ssdbox_ctx *ctx, const ssdbox_geom *geom, const
     return run_detect(ctx, sl, num_anchors, batch, nms_threshold, limit, src,
                       geom ? &geom->host : nullptr, d_img_wh, d_dets,
                       d_keep_idx, d_count);
+}
+
+extern "C" int ssdbox_decode_nms(ssdbox_ctx *ctx, const ssdbox_geom *geom, const float *d_anchors,
+                                 int64_t num_anchors, const float *d_y_pred, int batch,
+                                 float score_threshold, float nms_threshold, int limit,
+                                 const float *d_img_wh, float *d_dets, int32_t *d_keep_idx,
+                                 int32_t *d_count)
+{
+    return decode_nms_common(ctx, geom, d_anchors, num_anchors, d_y_pred, batch, score_threshold,
+                             nms_threshold, limit, d_img_wh, d_dets, d_keep_idx, d_count, false);
+}
+
+extern "C" int ssdbox_decode_nms_logits(ssdbox_ctx *ctx, const ssdbox_geom *geom, const float *d_anchors,
+                                        int64_t num_anchors, const float *d_y_logits, int batch,
+                                        float score_threshold, float nms_threshold, int limit,
+                                        const float *d_img_wh, float *d_dets, int32_t *d_keep_idx,
+                                        int32_t *d_count)
+{
+    return decode_nms_common(ctx, geom, d_anchors, num_anchors, d_y_logits, batch, score_threshold,
+                             nms_threshold, limit, d_img_wh, d_dets, d_keep_idx, d_count, true);
 }
 
 extern "C" int ssdbox_compute_nms(ssdbox_ctx *ctx, const float *d_boxes, const float *d_scores,
@@ -858,7 +900,9 @@ extern "C" int ssdbox_compute_nms(ssdbox_ctx *ctx, const float *d_boxes, const f
     src.y_pred = nullptr;
     src.boxes = reinterpret_cast<const float4 *>(d_boxes);
     src.scores = d_scores;
+    src.logits = 0;
     ScoreLayout sl;
+    sl.logits = false;
     sl.scores = d_scores;
     sl.img_stride = 0;
     sl.elem_stride = 1;

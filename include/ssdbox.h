@@ -129,6 +129,17 @@ int ssdbox_decode_nms(ssdbox_ctx *ctx, const ssdbox_geom *geom, const float *d_a
                       const float *d_img_wh, float *d_dets, int32_t *d_keep_idx,
                       int32_t *d_count);
 
+/* The same with the class columns of the head BEFORE the softmax of models/ssd.py:95 (what
+ * inference.py:40 would compute with its commented-out tf.math.softmax): d_y_logits
+ * (batch,A,6) = [logit_bg, logit_face, tx, ty, tw, th].  The score of an anchor is
+ * exp(l1 - m) * (1 / (exp(l0 - m) + exp(l1 - m))) with m = max(l0, l1), each step rounded
+ * to float32; everything after that is ssdbox_decode_nms. */
+int ssdbox_decode_nms_logits(ssdbox_ctx *ctx, const ssdbox_geom *geom, const float *d_anchors,
+                             int64_t num_anchors, const float *d_y_logits, int batch,
+                             float score_threshold, float nms_threshold, int limit,
+                             const float *d_img_wh, float *d_dets, int32_t *d_keep_idx,
+                             int32_t *d_count);
+
 /* utils/box_utils.py:184-222 (compute_nms) on caller-supplied boxes: d_boxes (n,4)
  * corners, d_scores (n).  Writes the kept indices into the input arrays, in kept order,
  * to d_keep (min(limit,n) int32) and their number to d_count (1 int32).  n == 0 yields

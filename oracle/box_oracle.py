@@ -229,6 +229,18 @@ def compute_nms_fast(boxes, scores, nms_threshold, limit=200):
     return order[np.array(selected)].astype(np.int32)
 
 
+def softmax2(y_logits):
+    """Class activation of the head, reference models/ssd.py:95: softmax over the two class
+    columns of (..., 6) rows [logit_bg, logit_face, 4 offsets], float32, evaluated as TF does
+    (exp of the shifted logits times the reciprocal of their sum)."""
+    y = np.array(y_logits, F32)
+    c = y[..., :2]
+    e = np.exp(c - np.max(c, axis=-1, keepdims=True)).astype(F32)
+    inv = (F32(1.0) / np.sum(e, axis=-1, keepdims=True, dtype=F32)).astype(F32)
+    y[..., :2] = e * inv
+    return y
+
+
 def postprocess(y_pred_image, anchors, conf_thresh, img_width=1.0, img_height=1.0,
                 nms_threshold=0.45, limit=1000, nms=compute_nms):
     """Inference-side caller tail for one image, inference.py:33-83.

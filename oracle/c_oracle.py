@@ -57,6 +57,8 @@ def lib():
         L.orc_postprocess.restype = ctypes.c_int
         L.orc_postprocess.argtypes = [c_f, c_f, ctypes.c_int64, ctypes.c_float, ctypes.c_float,
                                       ctypes.c_int, ctypes.c_float, ctypes.c_float, c_f, c_i]
+        L.orc_softmax2.restype = None
+        L.orc_softmax2.argtypes = [c_f, ctypes.c_int64, c_f]
         L.orc_ssd_loss.restype = ctypes.c_int
         L.orc_ssd_loss.argtypes = [c_f, c_f, ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
                                    ctypes.c_float, c_f, ctypes.POINTER(ctypes.c_ubyte), c_f, c_f,
@@ -171,6 +173,14 @@ def postprocess(y_pred_image, anchors, conf_thresh, img_width=1.0, img_height=1.
                               img_width, img_height, dets.ctypes.data_as(c_f),
                               idx.ctypes.data_as(c_i))
     return dets[:k].copy(), idx[:k].copy()
+
+
+def softmax2(y_logits):
+    """(..., 6) head rows with raw class logits -> the same rows with softmaxed class columns."""
+    y, py = _f(y_logits)
+    out = np.empty_like(y)
+    lib().orc_softmax2(py, y.size // 6, out.ctypes.data_as(c_f))
+    return out
 
 
 def ssd_loss(y_true, y_pred, neg_pos_ratio=3, n_neg_min=0, alpha=1.0, grad=False):

@@ -305,6 +305,23 @@ int orc_nms(const float *boxes, const float *scores, int64_t n, float thr, int l
 /* inference.py:33-83 for one image: y_pred (A,6) [bg, face, tx, ty, tw, th].
  * dets rows are [1, score, xmin, ymin, xmax, ymax] clipped to [0,1] then scaled; idx are
  * the kept anchor indices.  Both must hold `limit` rows.  Returns the count. */
+/* The head's class activation for two classes (reference models/ssd.py:95, Keras softmax over
+ * the last axis; TF 2.4 evaluates it as exp(x - max) * (1 / sum exp(x - max)) in float32).
+ * rows6 (rows, 6) in, out (rows, 6): columns 0 and 1 replaced by their softmax. */
+void orc_softmax2(const float *rows6, int64_t rows, float *out)
+{
+    for (int64_t i = 0; i < rows; ++i) {
+        const float *r = rows6 + i * 6;
+        float *o = out + i * 6;
+        const float m = fmaxf(r[0], r[1]);
+        const float e0 = orc_expf(r[0] - m), e1 = orc_expf(r[1] - m);
+        const float inv = 1.0f / (e0 + e1);
+        o[0] = e0 * inv;
+        o[1] = e1 * inv;
+        for (int c = 2; c < 6; ++c) o[c] = r[c];
+    }
+}
+
 int orc_postprocess(const float *y_pred, const float *anchors, int64_t A, float conf_thr,
                     float nms_thr, int limit, float img_w, float img_h, float *dets,
                     int32_t *idx)

@@ -229,6 +229,40 @@ def test_decode_nms_against_numpy_oracle(fda):
         np.testing.assert_allclose(dets[b, :n], n_dets, rtol=1e-5, atol=1e-6)
 
 
+def test_decode_nms_from_logits(fda):
+    """Class columns before the softmax of models/ssd.py:95: same detections, bit for bit, as
+    the softmaxed rows (C oracle's softmax) through the ordinary entry point; even anchor
+    counts take the 16-byte select kernel, odd ones the strided one."""
+    rng = np.random.default_rng(16)
+    cfg = ssd_config(128)
+    anchors_np = O.generate_anchors(cfg)
+    boxes, _, counts = S.make_ground_truth(rng, 4, 128, gmax=24)
+    y = S.make_head_outputs(rng, cfg, boxes, counts, n_ties=40)
+    p1 = np.clip(y[..., 1].astype(np.float64), 1e-7, 1 - 1e-7)
+    logits = y.copy()
+    logits[..., 0] = rng.normal(0, 2, p1.shape)
+    logits[..., 1] = logits[..., 0] + np.log(p1 / (1 - p1))
+    logits[0, :7, :2] = [[0, 0], [-100, 100], [100, -100], [3, 3], [-0.0, 0.0], [88, 88], [-200, -200]]
+    soft = C.softmax2(logits)
+    np.testing.assert_allclose(soft, O.softmax2(logits), rtol=2e-6, atol=1e-30)
+    assert soft[0, 0, 1] == 0.5 and soft[0, 1, 1] == 1.0 and soft[0, 2, 1] == 0.0
+    wh = rng.uniform(100, 2000, (4, 2)).astype(F32)
+    for anchors, yl, ys in ((fda.anchor_utils.generate_anchors(cfg), logits, soft),
+                            (anchors_np, logits, soft),
+                            (anchors_np[:-1], logits[:, :-1], soft[:, :-1])):
+        for thr in (0.05, 0.0):
+            got = fda.decode_nms_batch(anchors, yl, thr, 0.45, 1000, wh, from_logits=True)
+            want = fda.decode_nms_batch(anchors, ys, thr, 0.45, 1000, wh)
+            for g, w in zip(got, want):
+                assert_bits_equal(g, w) if g.dtype == np.float32 else np.testing.assert_array_equal(g, w)
+            assert int(got[2].sum()) > 0
+    # and against the C oracle's post-processing of the softmaxed rows
+    c_dets, c_idx = C.postprocess(soft[1], anchors_np, 0.05, float(wh[1, 0]), float(wh[1, 1]), 0.45, 1000)
+    dets, keep, count = fda.decode_nms_batch(anchors_np, logits, 0.05, 0.45, 1000, wh, from_logits=True)
+    np.testing.assert_array_equal(keep[1, :int(count[1])], c_idx)
+    assert_bits_equal(dets[1, :int(count[1])], c_dets)
+
+
 def test_decode_nms_nothing_passes_and_everything_ties(fda):
     cfg = ssd_config(64)
     A = len(O.generate_anchors(cfg))

@@ -243,3 +243,20 @@ def test_y_true_layout():
     assert y.shape == (16, 6) and y.dtype == np.float32
     assert list(y[5, :2]) == [0, 1] and list(y[4, :2]) == [1, 0]
     np.testing.assert_array_equal(y[:, 2:], O.encode(anchors, np.repeat(gt, 16, 0)))
+
+
+def test_softmax2_hand_values_and_c_restatement():
+    """models/ssd.py:95 for two classes: equal logits give exactly 0.5 each, a gap of 200
+    saturates to exactly 0 / 1, the location columns pass through; C equals numpy to 2 ULP."""
+    from oracle import c_oracle as C
+    rows = np.array([[0, 0, 1, 2, 3, 4], [-100, 100, 0, 0, 0, 0], [5, 5, 0, 0, 0, 0],
+                     [0, np.log(3.0), 0, 0, 0, 0], [-3.5, 1.25, 9, 9, 9, 9]], np.float32)
+    for sm in (O.softmax2(rows), C.softmax2(rows)):
+        assert sm.dtype == np.float32 and sm.shape == rows.shape
+        assert sm[0, :2].tolist() == [0.5, 0.5] and sm[2, :2].tolist() == [0.5, 0.5]
+        assert sm[1, :2].tolist() == [0.0, 1.0]
+        np.testing.assert_allclose(sm[3, :2], [0.25, 0.75], rtol=3e-7)
+        np.testing.assert_array_equal(sm[:, 2:], rows[:, 2:])
+    rng = np.random.default_rng(3)
+    y = rng.normal(0, 4, (2, 500, 6)).astype(np.float32)
+    np.testing.assert_allclose(C.softmax2(y), O.softmax2(y), rtol=3e-7, atol=1e-37)

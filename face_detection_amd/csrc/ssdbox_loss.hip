@@ -12,10 +12,12 @@
 //
 //   pass1   per anchor: log-loss, smooth-L1, key -> scratch; per-image sums (double atomics);
 //           positives and nonzero negative losses counted; histogram of the top 11 key bits
-//   scan    k = min(max(ratio * n_pos, n_neg_min), n_nonzero); the digit where the count from
-//           the top crosses k                                   (again after each histogram)
-//   hist    histogram of the next digit among the keys that share the prefix (twice)
-//   count   keys equal to T per chunk, then an exclusive scan over the chunks
+//   hist    (twice) k = min(max(ratio * n_pos, n_neg_min), n_nonzero) and the digit where the
+//           count from the top of the previous histogram crosses what is still to be found,
+//           recomputed by every workgroup (2048 bins) instead of a launch of its own; then the
+//           histogram of the next digit among the keys that share the prefix
+//   count   the last digit -> T, how many keys equal to T to keep; those keys per chunk and
+//           per image
 //   final   mask, mined-negative sums, gradient
 //   finish  (pos + neg + alpha * loc) / max(1, n_pos) * batch per image
 #include "ssdbox_internal.h"
@@ -28,12 +30,13 @@ constexpr int kLB = 256;               // threads per workgroup
 constexpr int kPerThread = 8;          // anchors per thread and chunk
 constexpr int kBins = 2048;
 
+// Every field is written by one kernel (its first workgroup) and read by later ones only.
 struct LossState {
     double n_pos;                      // sum of the positives column (utils/losses.py:112)
     u64 n_nonzero;                     // nonzero negative log-losses (:123)
     long long k;                       // negatives to keep (:135-136)
-    long long k_rem;                   // of which still to find inside the current prefix
-    unsigned prefix, pmask;            // key bits fixed so far
+    long long k_rem[2];                // of which still to find under prefix[0] / prefix[1]
+    unsigned prefix[2];                // key bits fixed after the first / second digit
     unsigned threshold;                // key of the k-th largest value
     unsigned need_eq, count_eq;        // keys equal to it: to keep / present
 };
@@ -52,6 +55,7 @@ struct LossArgs {
     LossState *state;
     double *sums;                      // (batch, 4): positive log-loss, smooth-L1, mined log-loss
     unsigned *chunk_eq;                // (batch * blocks_per_image) keys equal to the threshold
+    unsigned *img_eq;                  // (batch) the same per image
     float *total;                      // (batch)
     unsigned char *keep;               // (batch, anchors) or NULL
     float *grad;                       // (batch, anchors, 6) or NULL
@@ -188,89 +192,88 @@ __global__ __launch_bounds__(kLB) void loss_pass1_kernel(const LossArgs p)
     flush_hist(s_hist, p.hist);
 }
 
-// One workgroup of 1024 threads: the digit of pass `pass` where the count from the top
-// crosses what is still to be found.
-__global__ __launch_bounds__(1024) void loss_scan_kernel(const LossArgs p, int pass)
+// The digit (bin) of a 2048-bin histogram where the count from the top crosses k_rem
+// (1 <= k_rem <= total count), the count above it and in it.  Every thread of the workgroup
+// calls it and gets the same answer.
+struct Digit {
+    unsigned digit, above, count;
+};
+
+SSD_DEV Digit find_digit(const unsigned *__restrict__ hist, long long k_rem, unsigned *s_wtot, unsigned *s_sel)
 {
-    __shared__ unsigned s_wtot[16];
-    __shared__ unsigned s_sel[3];
+    static_assert(kBins == 8 * kLB, "eight bins per thread");
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
-    LossState *st = p.state;
-    long long k_rem;
-    if (pass == 0) {
-        long long k = (long long)p.neg_pos_ratio * (long long)st->n_pos;      // :135-136
-        if (k < p.n_neg_min) k = p.n_neg_min;
-        if (k > (long long)st->n_nonzero) k = (long long)st->n_nonzero;
-        k_rem = k;
-        if (t == 0) {
-            st->k = k;
-            st->prefix = 0u;
-            st->pmask = 0u;
-        }
-    } else {
-        k_rem = st->k_rem;
-    }
-    if (k_rem <= 0) {                  // nothing to keep (:163 and k == 0)
-        if (t == 0) {
-            st->k_rem = 0;
-            st->need_eq = 0u;
-            st->count_eq = 0u;
-            st->threshold = 0xFFFFFFFFu;
-        }
-        return;
-    }
-    const int shift = pass == 0 ? 21 : (pass == 1 ? 10 : 0);
-    const unsigned dmask = pass == 2 ? 0x3FFu : 0x7FFu;
-    const unsigned *hist = p.hist + pass * kBins;
-    const unsigned h0 = hist[2 * t], h1 = hist[2 * t + 1];
-    const unsigned pair = h0 + h1;
-    unsigned incl = pair;              // suffix sum over this wave's higher lanes
+    const uint4 lo = reinterpret_cast<const uint4 *>(hist)[2 * t];
+    const uint4 hi = reinterpret_cast<const uint4 *>(hist)[2 * t + 1];
+    const unsigned h[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    unsigned sum = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sum += h[j];
+    unsigned incl = sum;               // suffix sum over this wave's higher lanes
     for (int o = 1; o < 64; o <<= 1) {
         const unsigned v = __shfl_down(incl, o);
         if (lane + o < 64) incl += v;
     }
     if (lane == 0) s_wtot[wave] = incl;
     __syncthreads();
-    unsigned above1 = incl - pair;     // keys in digits above 2t+1
-    for (int w = wave + 1; w < 16; ++w) above1 += s_wtot[w];
-    const unsigned above0 = above1 + h1;
-    if ((long long)above1 < k_rem && (long long)above1 + h1 >= k_rem) {
-        s_sel[0] = 2 * t + 1;
-        s_sel[1] = above1;
-        s_sel[2] = h1;
-    }
-    if ((long long)above0 < k_rem && (long long)above0 + h0 >= k_rem) {
-        s_sel[0] = 2 * t;
-        s_sel[1] = above0;
-        s_sel[2] = h0;
+    unsigned above = incl - sum;       // keys in the bins above this thread's eight
+    for (int w = wave + 1; w < kLB / 64; ++w) above += s_wtot[w];
+#pragma unroll
+    for (int j = 7; j >= 0; --j) {
+        if ((long long)above < k_rem && (long long)above + h[j] >= k_rem) {
+            s_sel[0] = 8u * t + j;
+            s_sel[1] = above;
+            s_sel[2] = h[j];
+        }
+        above += h[j];
     }
     __syncthreads();
-    if (t == 0) {
-        const unsigned prefix = st->prefix | (s_sel[0] << shift);
-        st->prefix = prefix;
-        st->pmask |= dmask << shift;
-        st->k_rem = k_rem - (long long)s_sel[1];
-        if (pass == 2) {
-            st->threshold = prefix;
-            st->need_eq = (unsigned)(k_rem - (long long)s_sel[1]);
-            st->count_eq = s_sel[2];
-        }
-    }
+    Digit d;
+    d.digit = s_sel[0];
+    d.above = s_sel[1];
+    d.count = s_sel[2];
+    __syncthreads();
+    return d;
 }
 
-// grid (blocks_per_image, batch): histogram of digit `pass` among the keys under the prefix
-__global__ __launch_bounds__(kLB) void loss_hist_kernel(const LossArgs p, int pass)
+// grid (blocks_per_image, batch): the digit of pass PASS - 1, then the histogram of digit PASS
+// among the keys under the prefix
+template <int PASS>
+__global__ __launch_bounds__(kLB) void loss_hist_kernel(const LossArgs p)
 {
     __shared__ unsigned s_hist[kBins];
+    __shared__ unsigned s_wtot[kLB / 64];
+    __shared__ unsigned s_sel[3];
     const int t = threadIdx.x;
     const int img = blockIdx.y;
-    if (p.state->k_rem <= 0) return;
+    const bool first = blockIdx.x == 0 && blockIdx.y == 0 && t == 0;
+    LossState *st = p.state;
+    long long k, k_rem;
+    unsigned prefix = 0u;
+    if (PASS == 1) {
+        k = (long long)p.neg_pos_ratio * (long long)st->n_pos;                 // :135-136
+        if (k < p.n_neg_min) k = p.n_neg_min;
+        if (k > (long long)st->n_nonzero) k = (long long)st->n_nonzero;
+        k_rem = k;
+        if (first) st->k = k;
+    } else {
+        k = st->k;
+        k_rem = st->k_rem[0];
+        prefix = st->prefix[0];
+    }
+    if (k <= 0) return;                // nothing to keep (:163 and k == 0)
+    const Digit d = find_digit(p.hist + (PASS - 1) * kBins, k_rem, s_wtot, s_sel);
+    prefix |= d.digit << (PASS == 1 ? 21 : 10);
+    const unsigned pmask = PASS == 1 ? 0xFFE00000u : 0xFFFFFC00u;
+    if (first) {
+        st->k_rem[PASS - 1] = k_rem - (long long)d.above;
+        st->prefix[PASS - 1] = prefix;
+    }
     for (int b = t; b < kBins; b += kLB) s_hist[b] = 0u;
     __syncthreads();
-    const unsigned prefix = p.state->prefix, pmask = p.state->pmask;
-    const int shift = pass == 1 ? 10 : 0;
-    const unsigned dmask = pass == 2 ? 0x3FFu : 0x7FFu;
+    const int shift = PASS == 1 ? 10 : 0;
+    const unsigned dmask = PASS == 2 ? 0x3FFu : 0x7FFu;
     const int a0 = blockIdx.x * p.chunk;
     const int a1 = min(a0 + p.chunk, p.num_anchors);
     for (int a = a0 + t; a < a1; a += kLB) {
@@ -278,54 +281,48 @@ __global__ __launch_bounds__(kLB) void loss_hist_kernel(const LossArgs p, int pa
         if ((key & pmask) == prefix) atomicAdd(&s_hist[(key >> shift) & dmask], 1u);
     }
     __syncthreads();
-    flush_hist(s_hist, p.hist + pass * kBins);
+    flush_hist(s_hist, p.hist + PASS * kBins);
 }
 
-// grid (blocks_per_image, batch): keys equal to the threshold in this chunk
+// grid (blocks_per_image, batch): the last digit, then the keys equal to the threshold in this
+// chunk (only when not all of them are kept)
 __global__ __launch_bounds__(kLB) void loss_count_eq_kernel(const LossArgs p)
 {
     __shared__ double s_red[kLB / 64];
+    __shared__ unsigned s_wtot[kLB / 64];
+    __shared__ unsigned s_sel[3];
     const int t = threadIdx.x;
     const int img = blockIdx.y;
     const int blk = img * p.blocks_per_image + (int)blockIdx.x;
-    const LossState st = *p.state;
-    unsigned n = 0;
-    if (st.k > 0 && st.need_eq < st.count_eq) {      // otherwise every equal key is kept
-        const int a0 = blockIdx.x * p.chunk;
-        const int a1 = min(a0 + p.chunk, p.num_anchors);
-        for (int a = a0 + t; a < a1; a += kLB)
-            n += (p.key[(long long)img * p.num_anchors + a] == st.threshold) ? 1u : 0u;
-    }
-    const double tot = block_sum((double)n, s_red);
-    if (t == 0) p.chunk_eq[blk] = (unsigned)tot;
-}
-
-// One workgroup: exclusive scan of chunk_eq in place.
-__global__ __launch_bounds__(1024) void loss_scan_eq_kernel(const LossArgs p)
-{
-    __shared__ unsigned s_wtot[16];
-    __shared__ unsigned s_carry;
-    const int t = threadIdx.x;
-    const int lane = t & 63, wave = t >> 6;
-    const int n = p.batch * p.blocks_per_image;
-    if (t == 0) s_carry = 0u;
-    __syncthreads();
-    for (int base = 0; base < n; base += 1024) {
-        const int i = base + t;
-        const unsigned v = i < n ? p.chunk_eq[i] : 0u;
-        unsigned incl = v;
-        for (int o = 1; o < 64; o <<= 1) {
-            const unsigned u = __shfl_up(incl, o);
-            if (lane >= o) incl += u;
+    const bool first = blockIdx.x == 0 && blockIdx.y == 0 && t == 0;
+    LossState *st = p.state;
+    if (st->k <= 0) {
+        if (first) {
+            st->threshold = 0xFFFFFFFFu;
+            st->need_eq = 0u;
+            st->count_eq = 0u;
         }
-        if (lane == 63) s_wtot[wave] = incl;
-        __syncthreads();
-        unsigned off = s_carry;
-        for (int w = 0; w < wave; ++w) off += s_wtot[w];
-        if (i < n) p.chunk_eq[i] = off + incl - v;
-        __syncthreads();
-        if (t == 1023) s_carry = off + incl;
-        __syncthreads();
+        return;
+    }
+    const long long k_rem = st->k_rem[1];
+    const Digit d = find_digit(p.hist + 2 * kBins, k_rem, s_wtot, s_sel);
+    const unsigned threshold = st->prefix[1] | d.digit;
+    const unsigned need_eq = (unsigned)(k_rem - (long long)d.above);
+    if (first) {
+        st->threshold = threshold;
+        st->need_eq = need_eq;
+        st->count_eq = d.count;
+    }
+    if (need_eq >= d.count) return;    // every equal key is kept: no order needed
+    unsigned n = 0;
+    const int a0 = blockIdx.x * p.chunk;
+    const int a1 = min(a0 + p.chunk, p.num_anchors);
+    for (int a = a0 + t; a < a1; a += kLB)
+        n += (p.key[(long long)img * p.num_anchors + a] == threshold) ? 1u : 0u;
+    const unsigned tot = (unsigned)block_sum((double)n, s_red);
+    if (t == 0 && tot != 0u) {
+        p.chunk_eq[blk] = tot;
+        atomicAdd(&p.img_eq[img], tot);
     }
 }
 
@@ -345,11 +342,16 @@ __global__ __launch_bounds__(kLB) void loss_final_kernel(const LossArgs p)
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int img = blockIdx.y;
-    const int blk = img * p.blocks_per_image + (int)blockIdx.x;
     const LossState st = *p.state;
     const bool any = st.k > 0;
     const bool ordered = any && st.need_eq < st.count_eq;
-    unsigned eq_before = ordered ? p.chunk_eq[blk] : 0u;     // equal keys in earlier chunks
+    unsigned eq_before = 0u;           // equal keys in earlier images and earlier chunks of this one
+    if (ordered) {
+        unsigned part = 0u;
+        for (int b = t; b < img; b += kLB) part += p.img_eq[b];
+        for (int c = t; c < (int)blockIdx.x; c += kLB) part += p.chunk_eq[img * p.blocks_per_image + c];
+        eq_before = (unsigned)block_sum((double)part, s_red);
+    }
     const double denom = st.n_pos > 1.0 ? st.n_pos : 1.0;     // :174
     const float scale = (float)(1.0 / denom);
     const int a0 = blockIdx.x * p.chunk;
@@ -455,6 +457,9 @@ __global__ __launch_bounds__(kLB) void loss_final_kernel(const LossArgs p)
     if (t == 0 && neg_cls != 0.0) atomicAdd(&p.sums[4 * img + 2], neg_cls);
 }
 
+// A launch of its own: a "last workgroup finishes" scheme inside the final kernel needs a
+// device-scope fence per workgroup, which writes back the L2 of the workgroup's XCD each time
+// (measured: 42 -> 116 us).
 __global__ __launch_bounds__(kLB) void loss_finish_kernel(const LossArgs p)
 {
     const int b = blockIdx.x * kLB + threadIdx.x;
@@ -489,9 +494,9 @@ extern "C" int ssdbox_ssd_loss(ssdbox_ctx *ctx, const float *d_y_true, const flo
     int rc = ensure_buffer((void **)&ctx->loss_key, &ctx->loss_key_cap, (size_t)n, sizeof(unsigned), false,
                            ctx->stream);
     if (rc != SSDBOX_OK) return rc;
-    // one block of small scratch: histograms, state, per-image sums, chunk counts
+    // one block of small scratch: histograms, state, per-image sums, chunk and image counts
     const size_t small_bytes = 3 * kBins * sizeof(unsigned) + 256 + (size_t)batch * 4 * sizeof(double) +
-                               (size_t)batch * bpi * sizeof(unsigned);
+                               (size_t)batch * bpi * sizeof(unsigned) + (size_t)batch * sizeof(unsigned);
     rc = ensure_buffer((void **)&ctx->loss_small, &ctx->loss_small_cap, small_bytes, 1, false, ctx->stream);
     if (rc != SSDBOX_OK) return rc;
     SSD_CHECK_HIP(hipMemsetAsync(ctx->loss_small, 0, small_bytes, ctx->stream));
@@ -513,6 +518,7 @@ extern "C" int ssdbox_ssd_loss(ssdbox_ctx *ctx, const float *d_y_true, const flo
     a.sums = reinterpret_cast<double *>(small + 3 * kBins * sizeof(unsigned) + 256);
     a.chunk_eq = reinterpret_cast<unsigned *>(small + 3 * kBins * sizeof(unsigned) + 256 +
                                               (size_t)batch * 4 * sizeof(double));
+    a.img_eq = a.chunk_eq + (size_t)batch * bpi;
     a.total = d_total;
     a.keep = d_keep;
     a.grad = d_grad;
@@ -528,13 +534,9 @@ extern "C" int ssdbox_ssd_loss(ssdbox_ctx *ctx, const float *d_y_true, const flo
         hipLaunchKernelGGL(loss_pass1_kernel<true>, grid, dim3(kLB), 0, ctx->stream, a);
     else
         hipLaunchKernelGGL(loss_pass1_kernel<false>, grid, dim3(kLB), 0, ctx->stream, a);
-    hipLaunchKernelGGL(loss_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, a, 0);
-    hipLaunchKernelGGL(loss_hist_kernel, grid, dim3(kLB), 0, ctx->stream, a, 1);
-    hipLaunchKernelGGL(loss_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, a, 1);
-    hipLaunchKernelGGL(loss_hist_kernel, grid, dim3(kLB), 0, ctx->stream, a, 2);
-    hipLaunchKernelGGL(loss_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, a, 2);
+    hipLaunchKernelGGL(loss_hist_kernel<1>, grid, dim3(kLB), 0, ctx->stream, a);
+    hipLaunchKernelGGL(loss_hist_kernel<2>, grid, dim3(kLB), 0, ctx->stream, a);
     hipLaunchKernelGGL(loss_count_eq_kernel, grid, dim3(kLB), 0, ctx->stream, a);
-    hipLaunchKernelGGL(loss_scan_eq_kernel, dim3(1), dim3(1024), 0, ctx->stream, a);
     if (pair)
         hipLaunchKernelGGL(loss_final_kernel<true>, grid, dim3(kLB), 0, ctx->stream, a);
     else

@@ -153,6 +153,16 @@ def test_hip_loss_edge_cases():
     c_total, c_keep, _, _ = C.ssd_loss(yt, yp_e)
     np.testing.assert_array_equal(keep, c_keep)
     np.testing.assert_allclose(total, c_total, rtol=1e-6)
+    # ... across many images and several chunks per image (tie order = flat index order)
+    yt_m, yp_m = make_batch(rng, 37, 4100, pos_rate=0.02)
+    yp_m[..., 0] = 0.75
+    yp_m[..., 1] = 0.25
+    total, keep = fda.ssd_loss_batch(yt_m, yp_m, neg_pos_ratio=5, return_keep=True)
+    c_total, c_keep, _, _ = C.ssd_loss(yt_m, yp_m, neg_pos_ratio=5)
+    np.testing.assert_array_equal(keep, c_keep)
+    np.testing.assert_allclose(total, c_total, rtol=1e-6)
+    flat = keep.reshape(-1)
+    assert flat.any() and not flat[np.flatnonzero(flat)[-1] + 1:].any()
     # zero probabilities are clipped, the gradient there is zero
     yp_z = yp.copy()
     yp_z[0, :50, 0] = 0.0

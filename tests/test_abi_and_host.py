@@ -114,3 +114,25 @@ def test_synthetic_generator_shapes_and_statistics():
     frac = (y[..., 1] > 0.05).mean()
     assert 0.015 < frac < 0.04
     assert ((y[..., 1] == 1.0).sum(1) >= 64).all()
+
+
+def test_utils_shim_leaves_the_other_reference_modules_importable(tmp_path):
+    """`utils` at the repo root shadows only anchor_utils / box_utils: a stand-in for the
+    reference tree (own files, not the reference's) keeps its utils.datasets importable, and
+    that module's `from utils.box_utils import ...` lands here."""
+    import subprocess
+    import sys
+    ref = tmp_path / "ref" / "utils"
+    ref.mkdir(parents=True)
+    (ref / "datasets.py").write_text("from utils.box_utils import compute_target\nMARK = 'ref-datasets'\n")
+    (ref / "box_utils.py").write_text("MARK = 'ref-box'\n")
+    code = ("import utils.datasets as d, utils.box_utils as b, utils.anchor_utils as a, os;"
+            "assert d.MARK == 'ref-datasets', d.__file__;"
+            "assert not hasattr(b, 'MARK') and callable(b.compute_target) and callable(a.generate_anchors);"
+            "assert d.compute_target is b.compute_target;"
+            "assert os.path.dirname(os.path.abspath(b.__file__)) == os.path.join(%r, 'utils');"
+            "print('ok')" % ROOT)
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, "-c", code], cwd=str(tmp_path / "ref"), env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr[-2000:]

@@ -192,8 +192,9 @@ def timed_loop(torch, dist, world, fn, steps, warmup):
 
 
 def stage_times(wl, steps):
-    """Average device time per launch of every kernel stage, from HIP events recorded on the
-    stream the kernels run on (one stream, so the numbers are not overlapped)."""
+    """Average device time per launch of every kernel stage, from HIP events the library
+    attaches to each launch on the stream it runs on (hipExtLaunchKernel: the events take the
+    kernel's own begin and end timestamps; one stream, so the numbers are not overlapped)."""
     slot = wl.slots[0]
     ctx = slot["ctx"]
     for _ in range(5):

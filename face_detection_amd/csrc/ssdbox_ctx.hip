@@ -47,10 +47,9 @@ int ensure_buffer(void **ptr, size_t *cap, size_t need, size_t elem_size, bool z
 }
 
 // ----------------------------------------------------------------------------- timing
-StageTimer::StageTimer(ssdbox_ctx *c, int stage) : ctx(c)
+bool acquire_events(ssdbox_ctx *ctx, hipEvent_t ev[2])
 {
-    if (!ctx->timing) return;
-    hipEvent_t ev[2] = {nullptr, nullptr};
+    ev[0] = ev[1] = nullptr;
     for (int i = 0; i < 2; ++i) {
         if (!ctx->event_pool.empty()) {
             ev[i] = ctx->event_pool.back();
@@ -59,7 +58,17 @@ StageTimer::StageTimer(ssdbox_ctx *c, int stage) : ctx(c)
             ev[i] = nullptr;
         }
     }
-    if (ev[0] == nullptr || ev[1] == nullptr) return;
+    if (ev[0] != nullptr && ev[1] != nullptr) return true;
+    for (int i = 0; i < 2; ++i)
+        if (ev[i] != nullptr) ctx->event_pool.push_back(ev[i]);
+    return false;
+}
+
+StageTimer::StageTimer(ssdbox_ctx *c, int stage) : ctx(c)
+{
+    if (!ctx->timing) return;
+    hipEvent_t ev[2];
+    if (!acquire_events(ctx, ev)) return;
     (void)hipEventRecord(ev[0], ctx->stream);
     stop = ev[1];
     ctx->records.push_back({stage, ev[0], ev[1]});

@@ -739,25 +739,23 @@ int run_detect(ssdbox_ctx *ctx, const ScoreLayout &sl, long long n, int batch, f
     int rc = ensure_detect_scratch(ctx, batch, nseg);
     if (rc != SSDBOX_OK) return rc;
     {
-        StageTimer timer(ctx, SSDBOX_STAGE_SELECT);
         dim3 grid((unsigned)((nseg + kSelBlock / 64 - 1) / (kSelBlock / 64)), batch);
         if (sl.rows6 && sl.logits) {
-            hipLaunchKernelGGL(select_rows6_kernel<true>, grid, dim3(kSelBlock), 0, ctx->stream,
-                               reinterpret_cast<const float4 *>(sl.scores), (int)n, sl.thr, ctx->cand,
-                               ctx->cand_count, nseg);
+            launch_stage(ctx, SSDBOX_STAGE_SELECT, select_rows6_kernel<true>, grid, dim3(kSelBlock),
+                         reinterpret_cast<const float4 *>(sl.scores), (int)n, sl.thr, ctx->cand,
+                         ctx->cand_count, nseg);
         } else if (sl.rows6) {
-            hipLaunchKernelGGL(select_rows6_kernel<false>, grid, dim3(kSelBlock), 0, ctx->stream,
-                               reinterpret_cast<const float4 *>(sl.scores), (int)n, sl.thr, ctx->cand,
-                               ctx->cand_count, nseg);
+            launch_stage(ctx, SSDBOX_STAGE_SELECT, select_rows6_kernel<false>, grid, dim3(kSelBlock),
+                         reinterpret_cast<const float4 *>(sl.scores), (int)n, sl.thr, ctx->cand,
+                         ctx->cand_count, nseg);
         } else {
-            hipLaunchKernelGGL(select_strided_kernel, grid, dim3(kSelBlock), 0, ctx->stream,
-                               sl.scores, sl.img_stride, sl.elem_stride, sl.elem_off, (int)n, sl.thr,
-                               sl.use_thr, sl.logits ? 1 : 0, ctx->cand, ctx->cand_count, nseg);
+            launch_stage(ctx, SSDBOX_STAGE_SELECT, select_strided_kernel, grid, dim3(kSelBlock),
+                         sl.scores, sl.img_stride, sl.elem_stride, sl.elem_off, (int)n, sl.thr,
+                         sl.use_thr, sl.logits ? 1 : 0, ctx->cand, ctx->cand_count, nseg);
         }
     }
     SSD_CHECK_HIP(hipGetLastError());
     {
-        StageTimer timer(ctx, SSDBOX_STAGE_TOPK);
         TopkArgs a;
         memset(&a, 0, sizeof(a));
         if (host_geom != nullptr) a.geom = *host_geom;
@@ -775,21 +773,19 @@ int run_detect(ssdbox_ctx *ctx, const ScoreLayout &sl, long long n, int batch, f
         a.sscores = ctx->sscores;
         a.sidx = ctx->sidx;
         a.keff = ctx->keff;
-        hipLaunchKernelGGL(topk_sort_kernel, dim3(batch), dim3(kTopkBlock), 0, ctx->stream, a);
+        launch_stage(ctx, SSDBOX_STAGE_TOPK, topk_sort_kernel, dim3(batch), dim3(kTopkBlock), a);
     }
     SSD_CHECK_HIP(hipGetLastError());
     {
-        StageTimer timer(ctx, SSDBOX_STAGE_NMS_MASK);
         const int kw = (limit + 63) / 64;
-        hipLaunchKernelGGL(nms_mask_kernel, dim3(kw * (kw + 1) / 2, batch), dim3(64), 0, ctx->stream,
-                           ctx->sboxes, ctx->keff, nms_thr, ctx->mask);
+        launch_stage(ctx, SSDBOX_STAGE_NMS_MASK, nms_mask_kernel, dim3(kw * (kw + 1) / 2, batch), dim3(64),
+                     ctx->sboxes, ctx->keff, nms_thr, ctx->mask);
     }
     SSD_CHECK_HIP(hipGetLastError());
     {
-        StageTimer timer(ctx, SSDBOX_STAGE_NMS_SCAN);
-        hipLaunchKernelGGL(nms_scan_kernel, dim3(batch), dim3(kLimit), 0, ctx->stream, ctx->mask,
-                           ctx->sboxes, ctx->sscores, ctx->sidx, ctx->keff, limit, d_img_wh, d_dets,
-                           d_keep, d_count);
+        launch_stage(ctx, SSDBOX_STAGE_NMS_SCAN, nms_scan_kernel, dim3(batch), dim3(kLimit), ctx->mask,
+                     ctx->sboxes, ctx->sscores, ctx->sidx, ctx->keff, limit, d_img_wh, d_dets,
+                     d_keep, d_count);
     }
     SSD_CHECK_HIP(hipGetLastError());
     return SSDBOX_OK;

@@ -2,6 +2,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include <string>
@@ -150,6 +151,26 @@ struct StageTimer {
     StageTimer(ssdbox_ctx *c, int stage);
     ~StageTimer();
 };
+
+// Two events for one timed launch (from the context's pool), or false.
+bool acquire_events(ssdbox_ctx *ctx, hipEvent_t ev[2]);
+
+// One kernel launch on the context's stream.  With timing on, the launch itself carries the
+// two events, which then hold the kernel's own begin and end timestamps: the elapsed time is
+// the kernel's execution time, without the gaps an event pair recorded around it includes.
+template <typename... KArgs, typename... Args>
+void launch_stage(ssdbox_ctx *ctx, int stage, void (*kernel)(KArgs...), dim3 grid, dim3 block,
+                  Args &&...args)
+{
+    hipEvent_t ev[2];
+    if (ctx->timing && acquire_events(ctx, ev)) {
+        hipExtLaunchKernelGGL<KArgs...>(kernel, grid, block, 0u, ctx->stream, ev[0], ev[1], 0u,
+                                        static_cast<KArgs>(args)...);
+        ctx->records.push_back({stage, ev[0], ev[1]});
+    } else {
+        hipLaunchKernelGGL(kernel, grid, block, 0, ctx->stream, static_cast<KArgs>(args)...);
+    }
+}
 
 int ensure_buffer(void **ptr, size_t *cap, size_t need, size_t elem_size, bool zero,
                   hipStream_t stream);

@@ -515,26 +515,18 @@ template <bool GEOM, bool YTRUE>
 int launch_match(ssdbox_ctx *ctx, const MatchArgs &args, int batch, int n_tiles)
 {
     if (GEOM) {
-        StageTimer timer(ctx, SSDBOX_STAGE_SHAPES);
         const int items = args.geom.col_total + args.geom.rowk_total + args.gmax * args.geom.k_total;
-        hipLaunchKernelGGL(prep_kernel, dim3((items + kBlock - 1) / kBlock, batch), dim3(kBlock), 0,
-                           ctx->stream, args);
+        launch_stage(ctx, SSDBOX_STAGE_SHAPES, prep_kernel, dim3((items + kBlock - 1) / kBlock, batch),
+                     dim3(kBlock), args);
     }
     SSD_CHECK_HIP(hipGetLastError());
-    {
-        StageTimer timer(ctx, SSDBOX_STAGE_MATCH);
-        const dim3 grid(n_tiles, batch);
-        if (args.match_idx != nullptr || args.match_iou != nullptr)
-            hipLaunchKernelGGL((match_kernel<GEOM, YTRUE, true>), grid, dim3(kBlock), 0, ctx->stream, args);
-        else
-            hipLaunchKernelGGL((match_kernel<GEOM, YTRUE, false>), grid, dim3(kBlock), 0, ctx->stream, args);
-    }
+    const dim3 grid(n_tiles, batch);
+    if (args.match_idx != nullptr || args.match_iou != nullptr)
+        launch_stage(ctx, SSDBOX_STAGE_MATCH, match_kernel<GEOM, YTRUE, true>, grid, dim3(kBlock), args);
+    else
+        launch_stage(ctx, SSDBOX_STAGE_MATCH, match_kernel<GEOM, YTRUE, false>, grid, dim3(kBlock), args);
     SSD_CHECK_HIP(hipGetLastError());
-    {
-        StageTimer timer(ctx, SSDBOX_STAGE_FORCE);
-        hipLaunchKernelGGL((force_kernel<GEOM, YTRUE>), dim3(batch), dim3(kBlock), 0, ctx->stream,
-                           args);
-    }
+    launch_stage(ctx, SSDBOX_STAGE_FORCE, force_kernel<GEOM, YTRUE>, dim3(batch), dim3(kBlock), args);
     SSD_CHECK_HIP(hipGetLastError());
     return SSDBOX_OK;
 }

@@ -80,8 +80,8 @@ struct ssdbox_ctx {
     unsigned long long *gkey;
     size_t gkey_cap;               // entries
     bool gkey_dirty;
-    // match scratch: log-size offsets of every (image, GT box, box shape) triple
-    float2 *shape_tab;
+    // match scratch: box centre and log-size offsets of every (image, GT box, box shape) triple
+    float4 *shape_tab;
     size_t shape_cap;
     // match scratch: offsets of every anchor column (x) and (row, shape) pair (y) against
     // box 0 of each image

@@ -4,7 +4,8 @@
 //
 // Kernel 0 (prep_kernel, geometry mode): everything in the encoding that does not depend on
 // the single anchor, once per image instead of once per anchor --
-//   * log(box size / anchor size) / 0.2 for every (ground-truth box, anchor shape) pair;
+//   * the box centre and log(box size / anchor size) / 0.2 for every (ground-truth box, anchor
+//     shape) pair, one 16-byte entry: what an anchor matched to that box gathers;
 //   * the x offset against box 0 for every anchor column and the y offset against box 0 for
 //     every (feature-map row, anchor shape) pair: anchors that overlap nothing match box 0,
 //     and that is most of them.
@@ -70,7 +71,7 @@ struct MatchArgs {
     int *match_idx;
     float *match_iou;
     u64 *gkey;
-    float2 *shape_tab;             // (batch, gmax, geom.k_total), see prep_kernel
+    float4 *shape_tab;             // (batch, gmax, geom.k_total), see prep_kernel
     float *b0_tab;                 // (batch, geom.col_total + geom.rowk_total), see prep_kernel
 };
 
@@ -166,7 +167,8 @@ __global__ __launch_bounds__(kBlock) void prep_kernel(const MatchArgs p)
     const int k = s - g.layer[m].k_off;
     const float4 b = gt[gi];
     p.shape_tab[((long long)img * p.gmax + gi) * kt + s] =
-        make_float2(ssd_logf((b.z - b.x) / g.layer[m].bw[k]) / 0.2f,
+        make_float4((b.x + b.z) / 2.0f, (b.y + b.w) / 2.0f,
+                    ssd_logf((b.z - b.x) / g.layer[m].bw[k]) / 0.2f,
                     ssd_logf((b.w - b.y) / g.layer[m].bh[k]) / 0.2f);
 }
 
@@ -182,7 +184,7 @@ SSD_DEV void match_tile(const MatchArgs &p, MatchShared &sm, int m)
     const float4 *gt = p.gt_boxes + (long long)img * p.gmax;
     u64 *gkey = p.gkey + (long long)img * p.gmax;
     const float *labels = p.gt_labels + (long long)img * p.gmax;
-    const float2 *shapes = p.shape_tab + (long long)img * p.gmax * p.geom.k_total;
+    const float4 *shapes = p.shape_tab + (long long)img * p.gmax * p.geom.k_total;
 
     // The count and the first 256 boxes are fetched together with everything else the
     // prologue reads, so a tile pays one memory round trip before it can start.
@@ -221,7 +223,7 @@ SSD_DEV void match_tile(const MatchArgs &p, MatchShared &sm, int m)
         ah = col.z;
         tx0 = ld_off<float>(b0, ci * 4u);
         shape = (unsigned)L.k_off + k;
-        twh0 = ld_off<float2>(shapes, shape * 8u);
+        twh0 = ld_off<float2>(shapes, shape * 16u + 8u);
         const unsigned rowslot = lane >> 5;
         const bool col_ok = c < (unsigned)L.row_anchors;
         // a wave whose band starts below the map reads the padding of the last rows only
@@ -414,8 +416,7 @@ SSD_DEV void match_tile(const MatchArgs &p, MatchShared &sm, int m)
     // The decisions below are per wave and row (not per lane), which keeps the loads of all
     // rows in flight together.
     float lab[R];
-    float4 gb[R];
-    float2 twh[R];
+    float4 gb[R];                  // the matched box (anchor array) / its table entry (geometry)
     bool far[R];                   // some lane of the wave matched row i to a box other than 0
 #pragma unroll
     for (int i = 0; i < R; ++i) {
@@ -423,8 +424,8 @@ SSD_DEV void match_tile(const MatchArgs &p, MatchShared &sm, int m)
         if (__ballot(valid[i] && !(best[i] < p.thr)) != 0ull) lab[i] = ld_off<float>(labels, (unsigned)bidx[i] * 4u);
         far[i] = !GEOM || __ballot(valid[i] && bidx[i] != 0) != 0ull;
         if (far[i]) {
-            gb[i] = ld_off<float4>(gt, (unsigned)bidx[i] * 16u);
-            if (GEOM) twh[i] = ld_off<float2>(shapes, ((unsigned)bidx[i] * (unsigned)p.geom.k_total + shape) * 8u);
+            gb[i] = GEOM ? ld_off<float4>(shapes, ((unsigned)bidx[i] * (unsigned)p.geom.k_total + shape) * 16u)
+                         : ld_off<float4>(gt, (unsigned)bidx[i] * 16u);
         }
     }
     float conf[R];
@@ -435,9 +436,8 @@ SSD_DEV void match_tile(const MatchArgs &p, MatchShared &sm, int m)
         if (GEOM) {
             tgt[i] = make_float4(tx0, ty0[i], twh0.x, twh0.y);
             if (far[i]) {
-                const float4 e = make_float4(((gb[i].x + gb[i].z) / 2.0f - acx) / (aw * 0.1f),
-                                             ((gb[i].y + gb[i].w) / 2.0f - acy[i]) / (ah * 0.1f),
-                                             twh[i].x, twh[i].y);
+                const float4 e = make_float4((gb[i].x - acx) / (aw * 0.1f), (gb[i].y - acy[i]) / (ah * 0.1f),
+                                             gb[i].z, gb[i].w);
                 if (bidx[i] != 0) tgt[i] = e;
             }
         } else {
@@ -570,7 +570,7 @@ int match_common(ssdbox_ctx *ctx, const ssdbox_geom *geom, const float *d_anchor
     }
     if (geom != nullptr) {
         rc = ensure_buffer((void **)&ctx->shape_tab, &ctx->shape_cap, need * (size_t)geom->host.k_total,
-                           sizeof(float2), false, ctx->stream);
+                           sizeof(float4), false, ctx->stream);
         if (rc != SSDBOX_OK) return rc;
         rc = ensure_buffer((void **)&ctx->b0_tab, &ctx->b0_cap,
                            (size_t)batch * (size_t)(geom->host.col_total + geom->host.rowk_total),

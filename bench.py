@@ -461,7 +461,7 @@ def main():
             "decode_nms_images_per_s": args.batch * args.steps * world / t_det,
             "decode_nms_thr0_images_per_s": args.batch * n_det0 * world / t_det0,
             "kernel_us_thr0": {k: round(v, 2) for k, v in stages0.items()
-                               if k in ("select", "topk", "nms_mask", "nms_scan")},
+                               if k in ("select", "prune", "topk", "nms_mask", "nms_scan")},
             "hbm_copy_GBs": hbm_copy_rate(torch),
             "ssd_loss_fwd_bwd_images_per_s": args.batch * n_loss * world / t_loss,
             "ssd_loss_fwd_bwd_ms": t_loss / n_loss * 1e3,

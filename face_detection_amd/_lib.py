@@ -16,9 +16,9 @@ ERR_HIP = -2
 ERR_NOMEM = -3
 ERR_UNSUPPORTED = -4
 
-NUM_STAGES = 9
+NUM_STAGES = 10
 STAGE_NAMES = ("match", "force", "select", "topk", "nms_mask", "nms_scan", "elementwise", "shapes",
-               "loss")
+               "loss", "prune")
 MAX_NMS_LIMIT = 1024
 MAX_GT = 4096
 MAX_LAYERS = 8

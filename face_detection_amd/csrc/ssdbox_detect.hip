@@ -120,6 +120,117 @@ __global__ __launch_bounds__(kSelBlock) void select_strided_kernel(
     if (lane == 0) seg_count[(long long)img * nseg + seg] = off;
 }
 
+// -------------------------------------------------------------------------------- prune
+// When most anchors are candidates (threshold 0 as in reference evaluation.py:67, or a large
+// caller-supplied score array) one workgroup per image would spend its time reading hundreds
+// of kilobytes of keys twice.  Two small grid-wide kernels cut the candidates down first:
+//   cand_hist_kernel     per-image histogram of a monotone 2048-bin map of the keys
+//   cand_prune_kernel    every workgroup finds the bin where the count from the top crosses
+//                        `limit`; every wave rewrites its own segment with the keys at or above
+//                        that bin (all of the `limit` largest keys are among them)
+// The top-k kernel then runs unchanged on what is left.
+constexpr int kHistSegs = 16;              // segments per workgroup of cand_hist_kernel
+
+// Monotone non-decreasing map from rank key to one of kBins bins: linear in the score when the
+// scores are known to lie in [lo, lo + 2047 / scale], the leading key bits otherwise.
+SSD_DEV int prune_bin(u64 key, int has_range, float lo, float scale)
+{
+    if (!has_range) return (int)(key >> 53);
+    const uint32_t u = (uint32_t)(key >> 32);
+    if (u == 0u) return 0;                                        // NaN scores rank last
+    const uint32_t b = (u & 0x80000000u) ? (u ^ 0x80000000u) : ~u;  // undo score_key
+    const float x = (u2f(b) - lo) * scale;
+    return (int)fminf(fmaxf(x, 0.0f), (float)(kBins - 1));
+}
+
+__global__ __launch_bounds__(kSelBlock) void cand_hist_kernel(const u64 *__restrict__ cand,
+                                                              const int *__restrict__ seg_count, int nseg,
+                                                              int has_range, float lo, float scale,
+                                                              unsigned int *__restrict__ hist)
+{
+    __shared__ unsigned int s_hist[kBins];
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int img = blockIdx.y;
+    for (int b = t; b < kBins; b += kSelBlock) s_hist[b] = 0u;
+    __syncthreads();
+    const int s_end = min(((int)blockIdx.x + 1) * kHistSegs, nseg);
+    for (int s = blockIdx.x * kHistSegs + wave; s < s_end; s += kSelBlock / 64) {
+        const int cnt = seg_count[(long long)img * nseg + s];
+        const u64 *src = cand + ((long long)img * nseg + s) * kSeg;
+        u64 key[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) key[q] = src[min(q * 64 + lane, max(cnt - 1, 0))];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (q * 64 + lane < cnt) atomicAdd(&s_hist[prune_bin(key[q], has_range, lo, scale)], 1u);
+    }
+    __syncthreads();
+    for (int b = t; b < kBins; b += kSelBlock) {
+        const unsigned int c = s_hist[b];
+        if (c != 0u) atomicAdd(&hist[(long long)img * kBins + b], c);
+    }
+}
+
+// grid (ceil(nseg / 4), batch), one wave per segment
+__global__ __launch_bounds__(kSelBlock) void cand_prune_kernel(u64 *__restrict__ cand,
+                                                               int *__restrict__ seg_count, int nseg,
+                                                               int limit, int has_range, float lo, float scale,
+                                                               const unsigned int *__restrict__ hist)
+{
+    static_assert(kBins == 8 * kSelBlock, "eight bins per thread");
+    __shared__ unsigned int s_wtot[kSelBlock / 64];
+    __shared__ int s_cut;
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int img = blockIdx.y;
+    const int seg = blockIdx.x * (kSelBlock / 64) + wave;
+    // the segment's keys are fetched first: the cut does not depend on them
+    const int cnt = (seg < nseg) ? seg_count[(long long)img * nseg + seg] : 0;
+    u64 *mine = cand + ((long long)img * nseg + min(seg, nseg - 1)) * kSeg;
+    u64 key[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) key[q] = mine[min(q * 64 + lane, max(cnt - 1, 0))];
+
+    // the bin where the count from the top reaches min(total, limit)
+    const uint4 lo4 = reinterpret_cast<const uint4 *>(hist + (long long)img * kBins)[2 * t];
+    const uint4 hi4 = reinterpret_cast<const uint4 *>(hist + (long long)img * kBins)[2 * t + 1];
+    const unsigned int h[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+    unsigned int sum = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sum += h[j];
+    unsigned int incl = sum;           // suffix sum over this wave's higher lanes
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned int v = __shfl_down(incl, o);
+        if (lane + o < 64) incl += v;
+    }
+    if (lane == 0) s_wtot[wave] = incl;
+    if (t == 0) s_cut = 0;             // fewer candidates than `limit`: everything stays
+    __syncthreads();
+    unsigned int above = incl - sum;
+    for (int w = wave + 1; w < kSelBlock / 64; ++w) above += s_wtot[w];
+#pragma unroll
+    for (int j = 7; j >= 0; --j) {
+        if (above < (unsigned int)limit && above + h[j] >= (unsigned int)limit) s_cut = 8 * t + j;
+        above += h[j];
+    }
+    __syncthreads();
+    const int cut = s_cut;
+    if (seg >= nseg || cut == 0) return;
+
+    // this wave's segment, rewritten in place with the keys at or above the cut
+    const u64 lt = (1ull << lane) - 1ull;
+    int off = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const bool pass = (q * 64 + lane < cnt) && prune_bin(key[q], has_range, lo, scale) >= cut;
+        const u64 bal = __ballot(pass);
+        if (pass) mine[off + __popcll(bal & lt)] = key[q];
+        off += __popcll(bal);
+    }
+    if (lane == 0) seg_count[(long long)img * nseg + seg] = off;
+}
+
 // ------------------------------------------------------------------------- top-k + sort
 struct BoxSource {
     int mode;                     // 0: decode, anchors from geometry; 1: decode, anchor array; 2: gather
@@ -150,14 +261,7 @@ struct TopkArgs {
 };
 
 // Monotone non-decreasing map from rank key to one of kBins linear score bins.
-SSD_DEV int linear_bin(u64 key, float lo, float scale)
-{
-    const uint32_t u = (uint32_t)(key >> 32);
-    if (u == 0u) return 0;                                        // NaN scores rank last
-    const uint32_t b = (u & 0x80000000u) ? (u ^ 0x80000000u) : ~u;  // undo score_key
-    const float x = (u2f(b) - lo) * scale;
-    return (int)fminf(fmaxf(x, 0.0f), (float)(kBins - 1));
-}
+SSD_DEV int linear_bin(u64 key, float lo, float scale) { return prune_bin(key, 1, lo, scale); }
 
 // Current bucket of the select: keys whose linear bin (if used) and leading key bits match.
 struct Bucket {
@@ -695,6 +799,9 @@ int ensure_detect_scratch(ssdbox_ctx *ctx, int batch, long long nseg)
     rc = ensure_buffer((void **)&ctx->cand_count, &ctx->count_cap, (size_t)batch * (size_t)nseg,
                        sizeof(int), false, ctx->stream);
     if (rc != SSDBOX_OK) return rc;
+    rc = ensure_buffer((void **)&ctx->cand_hist, &ctx->hist_cap, (size_t)batch * kBins, sizeof(unsigned int),
+                       false, ctx->stream);
+    if (rc != SSDBOX_OK) return rc;
     if ((size_t)batch > ctx->det_cap) {
         SSD_CHECK_HIP(hipStreamSynchronize(ctx->stream));
         void *old[] = {ctx->sboxes, ctx->sscores, ctx->sidx, ctx->keff, ctx->mask};
@@ -755,6 +862,23 @@ int run_detect(ssdbox_ctx *ctx, const ScoreLayout &sl, long long n, int batch, f
         }
     }
     SSD_CHECK_HIP(hipGetLastError());
+    // head scores are softmax outputs: spread the linear bins over (threshold, 1]
+    const int has_range = (sl.use_thr && sl.thr >= 0.0f && sl.thr < 1.0f) ? 1 : 0;
+    const float range_lo = has_range ? sl.thr : 0.0f;
+    const float range_scale = has_range ? (float)(kBins - 1) / (1.0f - sl.thr) : 0.0f;
+    // Most anchors are candidates when there is no threshold or one below the usual detection
+    // thresholds: prune before the one-workgroup-per-image kernel (a guess about speed only,
+    // both ways give the same result).
+    if (n > kCap && (!sl.use_thr || sl.thr < 0.02f)) {
+        SSD_CHECK_HIP(hipMemsetAsync(ctx->cand_hist, 0, (size_t)batch * kBins * sizeof(unsigned int), ctx->stream));
+        launch_stage(ctx, SSDBOX_STAGE_PRUNE, cand_hist_kernel, dim3((nseg + kHistSegs - 1) / kHistSegs, batch),
+                     dim3(kSelBlock), ctx->cand, ctx->cand_count, nseg, has_range, range_lo, range_scale,
+                     ctx->cand_hist);
+        launch_stage(ctx, SSDBOX_STAGE_PRUNE, cand_prune_kernel,
+                     dim3((nseg + kSelBlock / 64 - 1) / (kSelBlock / 64), batch), dim3(kSelBlock), ctx->cand,
+                     ctx->cand_count, nseg, limit, has_range, range_lo, range_scale, ctx->cand_hist);
+        SSD_CHECK_HIP(hipGetLastError());
+    }
     {
         TopkArgs a;
         memset(&a, 0, sizeof(a));
@@ -764,10 +888,9 @@ int run_detect(ssdbox_ctx *ctx, const ScoreLayout &sl, long long n, int batch, f
         a.nseg = nseg;
         a.n_per_image = (int)n;
         a.limit = limit;
-        // head scores are softmax outputs: spread the linear bins over (threshold, 1]
-        a.has_range = (sl.use_thr && sl.thr >= 0.0f && sl.thr < 1.0f) ? 1 : 0;
-        a.lo = a.has_range ? sl.thr : 0.0f;
-        a.scale = a.has_range ? (float)(kBins - 1) / (1.0f - sl.thr) : 0.0f;
+        a.has_range = has_range;
+        a.lo = range_lo;
+        a.scale = range_scale;
         a.src = src;
         a.sboxes = ctx->sboxes;
         a.sscores = ctx->sscores;

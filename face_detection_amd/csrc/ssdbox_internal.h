@@ -99,6 +99,8 @@ struct ssdbox_ctx {
     size_t cand_cap;
     int *cand_count;               // (batch, segments) candidates per segment
     size_t count_cap;
+    unsigned int *cand_hist;       // (batch, 2048) score histogram for the pruning pass
+    size_t hist_cap;
     float4 *sboxes;                // (batch, LIMIT) decoded boxes in rank order
     float *sscores;
     int *sidx;

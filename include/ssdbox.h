@@ -49,7 +49,8 @@ enum {
     SSDBOX_STAGE_ELEMENTWISE = 6,
     SSDBOX_STAGE_SHAPES = 7,     /* per (GT box, anchor shape) log-size table before matching */
     SSDBOX_STAGE_LOSS = 8,       /* SSD loss with hard-negative mining (all its launches)    */
-    SSDBOX_NUM_STAGES = 9
+    SSDBOX_STAGE_PRUNE = 9,      /* candidate histogram + pruning when most anchors pass      */
+    SSDBOX_NUM_STAGES = 10
 };
 
 int ssdbox_version(void);

@@ -215,6 +215,22 @@ def test_decode_nms_small(fda, mode, thr):
     check_decode_nms(fda, cfg, y, thr, None, mode, limit=7)
 
 
+@pytest.mark.parametrize("thr", [0.0, 0.01, -1.0])
+def test_decode_nms_many_candidates(fda, thr):
+    """Thresholds below the usual ones (evaluation.py:67 uses 0): nearly every anchor is a
+    candidate and the candidates are pruned by a grid-wide histogram before the top-k."""
+    rng = np.random.default_rng(21)
+    cfg = ssd_config(256)
+    boxes, _, counts = S.make_ground_truth(rng, 3, 256, gmax=24)
+    y = S.make_head_outputs(rng, cfg, boxes, counts, n_ties=300)
+    y[1, :, 1] = 0.25                       # one image where every score ties
+    y[2, 100:, 1] = 0.0                     # one with fewer candidates than the limit at thr 0
+    assert y.shape[1] > 4096
+    check_decode_nms(fda, cfg, y, thr, None)
+    check_decode_nms(fda, cfg, y, thr, None, "array", limit=200)
+    check_decode_nms(fda, cfg, y, thr, None, limit=7)
+
+
 def test_decode_nms_against_numpy_oracle(fda):
     rng = np.random.default_rng(6)
     cfg = ssd_config(128)

@@ -324,6 +324,29 @@ def pcie_times(wl, reps=5):
     return {"h2d_ms": h2d * 1e3, "d2h_ms": d2h * 1e3, "h2d_bytes": nbytes_in, "d2h_bytes": nbytes_out}
 
 
+def single_image_latency(wl, reps=50):
+    """Batch 1 (one 640x640 head output, as reference inference.py processes images): wall time
+    of decode + threshold + top-k + NMS through the C ABI, input resident, nothing else in flight."""
+    torch = wl.torch
+    slot = wl.slots[0]
+    a = wl.args
+
+    def one():
+        rc = wl.lib.ssdbox_decode_nms(
+            slot["ctx"].handle, wl.g_handle, wl.a_ptr, wl.A, wl._p(wl.d_ypred), 1, a.score_thr, 0.45, 1000,
+            None, wl._p(slot["dets"]), wl._p(slot["keep"]), wl._p(slot["count"]))
+        if rc != 0:
+            wl.lib_mod.check(rc)
+    for _ in range(5):
+        one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        one()
+        torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
 def hbm_copy_rate(torch, nbytes=1 << 28, reps=20):
     """Achievable HBM bandwidth on this box: device-to-device copy of 256 MiB, read + write
     bytes per second (the roofline fractions are quoted against the nominal peak instead)."""
@@ -476,6 +499,7 @@ def main():
         }
         lat = single_batch_latency(wl)
         out["single_batch_latency_ms"] = lat * 1e3
+        out["single_image_decode_nms_latency_ms"] = single_image_latency(wl) * 1e3
         if allgather_ms is not None:
             out["allgather_detections_ms"] = allgather_ms
         pcie = pcie_times(wl)

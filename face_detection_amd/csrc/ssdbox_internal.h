@@ -54,7 +54,7 @@ struct ssdbox_geom {
     int device;
     GeomDev host;                  // host copy of what d_geom points to
     GeomDev *d_geom;
-    float4 *d_col;                 // per anchor column of every layer: cx, w, h, shape index bits
+    float4 *d_col;                 // per anchor column of every layer (padded by a tile): cx, w, h, 0
     float *d_cx;                   // concatenated per-layer column centres
     float *d_cy;                   // concatenated per-layer row centres
 };

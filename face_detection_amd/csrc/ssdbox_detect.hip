@@ -418,6 +418,29 @@ __global__ __launch_bounds__(kTopkBlock) void topk_sort_kernel(const TopkArgs p)
     bool in_lds = false;
     int m_lds = 0;
 
+    // Every candidate key still in global memory: by whole segments when they are well filled
+    // (threshold near 0), by a thread per segment when they hold a few keys each (more
+    // candidates than LDS takes only because the image has many anchors).
+    const bool dense = n >= nseg * 96;
+    auto for_each_key = [&](auto f) {
+        if (dense) {
+            for_each_candidate(cand, segc, nseg, wave, lane, f);
+            return;
+        }
+        for (int s = t; s < nseg; s += kTopkBlock) {
+            const int cnt = (s == t) ? cnt_first : segc[s];
+            const u64 *src = cand + (long long)s * kSeg;
+            for (int i0 = 0; i0 < cnt; i0 += 8) {
+                u64 k8[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) k8[u] = src[min(i0 + u, cnt - 1)];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (i0 + u < cnt) f(k8[u]);
+            }
+        }
+    };
+
     while (true) {
         if (!in_lds && n_above + bucket <= kCap) {
             // ---- stage every key at or above the bucket in LDS
@@ -441,7 +464,7 @@ __global__ __launch_bounds__(kTopkBlock) void topk_sort_kernel(const TopkArgs p)
                 }
                 if (t == 0) s_count = n;
             } else {
-                for_each_candidate(cand, segc, nseg, wave, lane, [&](u64 key) {
+                for_each_key([&](u64 key) {
                     if (above_bucket(bk, key, lo, scale) || in_bucket(bk, key, lo, scale))
                         s_keys[atomicAdd(&s_count, 1)] = key;
                 });
@@ -467,7 +490,7 @@ __global__ __launch_bounds__(kTopkBlock) void topk_sort_kernel(const TopkArgs p)
                                              : (int)((unsigned int)(key >> shift) & dmask)], 1u);
             }
         } else {
-            for_each_candidate(cand, segc, nseg, wave, lane, [&](u64 key) {
+            for_each_key([&](u64 key) {
                 if (in_bucket(bk, key, lo, scale))
                     atomicAdd(&s_hist[dg < 0 ? linear_bin(key, lo, scale)
                                              : (int)((unsigned int)(key >> shift) & dmask)], 1u);

@@ -31,7 +31,7 @@ constexpr int kSeg = 256;                  // candidate slots per segment = anch
 constexpr int kSelBlock = 256;
 constexpr int kLimit = SSDBOX_MAX_NMS_LIMIT;
 constexpr int kWords = kLimit / 64;
-constexpr int kCap = 4096;                 // keys the top-k kernel stages in LDS
+constexpr int kCap = 8192;                 // keys the top-k kernel stages in LDS
 constexpr int kBucketMax = 256;            // bucket size resolved by direct ranking
 constexpr int kBins = 2048;
 constexpr int kTopkBlock = 1024;

@@ -225,7 +225,7 @@ def test_decode_nms_many_candidates(fda, thr):
     y = S.make_head_outputs(rng, cfg, boxes, counts, n_ties=300)
     y[1, :, 1] = 0.25                       # one image where every score ties
     y[2, 100:, 1] = 0.0                     # one with fewer candidates than the limit at thr 0
-    assert y.shape[1] > 4096
+    assert y.shape[1] > 8192
     check_decode_nms(fda, cfg, y, thr, None)
     check_decode_nms(fda, cfg, y, thr, None, "array", limit=200)
     check_decode_nms(fda, cfg, y, thr, None, limit=7)
@@ -321,7 +321,7 @@ def clustered_boxes(rng, n):
     return np.concatenate([ctr - wh / 2, ctr + wh / 2], 1).astype(F32)
 
 
-@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 700, 1024, 1500, 2048, 2049, 5000, 70000])
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 700, 1024, 1500, 2048, 2049, 5000, 8192, 8193, 12000, 70000])
 def test_compute_nms_raw(fda, n):
     rng = np.random.default_rng(n)
     boxes = clustered_boxes(rng, n)

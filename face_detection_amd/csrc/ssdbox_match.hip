@@ -343,8 +343,11 @@ SSD_DEV void match_tile(const MatchArgs &p, MatchShared &sm, int m)
             if (!valid[i]) ay1[i] = -3.0e38f;
         }
 
+        float4 gb_next = sm.box[0];
         for (int q = 0; q < n_list; ++q) {
-            const float4 gb = sm.box[q];
+            // the next box is on its way from LDS while this one is evaluated
+            const float4 gb = gb_next;
+            gb_next = sm.box[min(q + 1, n_list - 1)];
             // compute_iou, utils/box_utils.py:35-42; the x overlap is shared by the rows
             const float iw = vmin(ax1, gb.z) - vmax(ax0, gb.x);
             // no lane of the wave can overlap this box: every IoU is +0, nothing to update

@@ -270,6 +270,18 @@ def cpu_baseline(args, inputs, n_images, workers=6):
             pool_rate = n / (time.perf_counter() - t0)
     except Exception as e:                                # the figure is optional
         print("cpu pool baseline skipped: %r" % (e,), file=sys.stderr)
+    # the scalar C restatement of the same algorithm (no (A,G) temporaries), one core
+    c_rate = None
+    try:
+        from oracle import c_oracle as CO
+        t0 = time.perf_counter()
+        for b in range(n):
+            g = int(gt_counts[b])
+            CO.compute_target(anchors, gt_boxes[b, :g], gt_labels[b, :g], float(args.size))
+            CO.postprocess(y_pred[b], anchors, args.score_thr, 1.0, 1.0, 0.45, 1000)
+        c_rate = n / (time.perf_counter() - t0)
+    except Exception as e:                                # the figure is optional
+        print("C oracle baseline skipped: %r" % (e,), file=sys.stderr)
     res = {
         "value": 1.0 / per_image, "unit": "images/sec", "cores": 1, "kind": "port",
         "sample": "%d images of this batch (G=%s): numpy literal oracle, match+encode %.3f s/img, "
@@ -277,6 +289,7 @@ def cpu_baseline(args, inputs, n_images, workers=6):
                   % (n, [int(x) for x in gt_counts[:n]], t_match / n, t_det / n, t_anchor),
         "match_encode_images_per_s": n / t_match, "decode_nms_images_per_s": n / t_det,
         "pool": {"workers": workers, "images_per_s": pool_rate},
+        "c_restatement_images_per_s": c_rate,
     }
     return res, outputs
 

@@ -27,7 +27,7 @@ namespace {
 typedef unsigned long long u64;
 
 constexpr int kLB = 256;               // threads per workgroup
-constexpr int kPerThread = 8;          // anchors per thread and chunk
+constexpr int kPerThread = 10;         // anchors per thread and chunk
 constexpr int kBins = 2048;
 
 // Every field is written by one kernel (its first workgroup) and read by later ones only.
@@ -149,9 +149,11 @@ __global__ __launch_bounds__(kLB) void loss_pass1_kernel(const LossArgs p)
     const int a1 = min(a0 + p.chunk, p.num_anchors);
     double pos_cls = 0.0, loc_s = 0.0, n_pos = 0.0;
     unsigned nonzero = 0;
-    for (int a = a0 + E * t; a < a1; a += E * kLB) {
-        const long long i = (long long)img * p.num_anchors + a;
-        Row yt[E], yp[E];
+    // The rows of the next round are requested before this round's keys are stored: loads and
+    // stores of a wave complete in issue order, so a load behind the store would also wait for
+    // the store to reach memory.
+    auto load_rows = [&](int a, Row *yt, Row *yp) {
+        const long long i = (long long)img * p.num_anchors + min(a, a1 - E);
         if (PAIR) {
             load_row_pair(p.y_true, i, yt[0], yt[E - 1]);
             load_row_pair(p.y_pred, i, yp[0], yp[E - 1]);
@@ -159,6 +161,13 @@ __global__ __launch_bounds__(kLB) void loss_pass1_kernel(const LossArgs p)
             yt[0] = load_row(p.y_true, i);
             yp[0] = load_row(p.y_pred, i);
         }
+    };
+    Row yt[E], yp[E];
+    load_rows(a0 + E * t, yt, yp);
+    for (int a = a0 + E * t; a < a1; a += E * kLB) {
+        const long long i = (long long)img * p.num_anchors + a;
+        Row yt_next[E], yp_next[E];
+        load_rows(a + E * kLB, yt_next, yp_next);          // clamped into the chunk past its end
         unsigned key[E];
 #pragma unroll
         for (int e = 0; e < E; ++e) {
@@ -177,6 +186,11 @@ __global__ __launch_bounds__(kLB) void loss_pass1_kernel(const LossArgs p)
             *reinterpret_cast<uint2 *>(p.key + i) = make_uint2(key[0], key[E - 1]);
         else
             p.key[i] = key[0];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            yt[e] = yt_next[e];
+            yp[e] = yp_next[e];
+        }
     }
     pos_cls = block_sum(pos_cls, s_red);
     loc_s = block_sum(loc_s, s_red);

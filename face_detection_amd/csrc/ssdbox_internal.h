@@ -87,6 +87,9 @@ struct ssdbox_ctx {
     // box 0 of each image
     float *b0_tab;
     size_t b0_cap;
+    // match scratch: images ordered by falling box count
+    int *img_order;
+    size_t order_cap;
 
     // loss scratch: rank keys of the negative log-losses; histograms, state, sums, chunk counts
     unsigned *loss_key;

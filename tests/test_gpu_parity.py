@@ -144,6 +144,23 @@ def test_match_edge_cases(fda):
         fda.box_utils.compute_target(grid, np.zeros((0, 4), F32), np.zeros((0,), F32))
 
 
+def test_match_encode_large_batch_image_order(fda):
+    """Images are processed in order of falling box count up to 4096 images per call and as
+    given beyond that: both sides of the limit, very uneven counts, results per image unchanged."""
+    cfg = ssd_config(64)
+    anchors_np = O.generate_anchors(cfg)
+    grid = fda.anchor_utils.generate_anchors(cfg)
+    for B in (4096, 4100):
+        rng = np.random.default_rng(B)
+        boxes, labels, counts = S.make_ground_truth(rng, B, 64, gmax=40)
+        conf, locs = fda.match_encode_batch(grid, boxes, counts, labels, 64.0)
+        for b in list(rng.choice(B, 12, replace=False)) + [0, B - 1, int(np.argmax(counts)), int(np.argmin(counts))]:
+            g = counts[b]
+            c_conf, c_locs = C.compute_target(anchors_np, boxes[b, :g], labels[b, :g], 64.0)
+            np.testing.assert_array_equal(conf[b], c_conf)
+            assert_bits_equal(locs[b], c_locs)
+
+
 def test_match_encode_full_size_batch32(fda):
     rng = np.random.default_rng(21)
     cfg = ssd_config(640)

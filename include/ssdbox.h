@@ -59,7 +59,7 @@ const char *ssdbox_last_error(void);
 /* ---- context ---------------------------------------------------------------------- */
 /* stream: a hipStream_t owned by the caller (e.g. torch's current stream; NULL is the
  * device's default stream).  With own_stream != 0 the argument is ignored and the context
- * creates and owns a non-blocking stream instead. */
+ * creates and owns a non-blocking stream instead, at the device's highest stream priority. */
 int ssdbox_ctx_create(int device, void *stream, int own_stream, ssdbox_ctx **out);
 int ssdbox_ctx_destroy(ssdbox_ctx *ctx);
 int ssdbox_ctx_set_stream(ssdbox_ctx *ctx, void *stream, int own_stream);

@@ -49,6 +49,7 @@ SIGNATURES = {
     "ssdbox_geom_layers": (_i, [_vp, _pi32, _pi32, _pi32]),
     "ssdbox_generate_anchors": (_i, [_vp, _vp, _vp]),
     "ssdbox_match_encode": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp, _vp]),
+    "ssdbox_match_encode_static": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp, _vp]),
     "ssdbox_match_encode_ytrue": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i, _i, _f, _f, _vp]),
     "ssdbox_decode_nms": (_i, [_vp, _vp, _vp, _i64, _vp, _i, _f, _f, _i, _vp, _vp, _vp, _vp]),
     "ssdbox_decode_nms_logits": (_i, [_vp, _vp, _vp, _i64, _vp, _i, _f, _f, _i, _vp, _vp, _vp, _vp]),

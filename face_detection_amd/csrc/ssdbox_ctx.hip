@@ -5,6 +5,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <new>
+
 #include "ssdbox_internal.h"
 
 static thread_local char g_err[512] = "";
@@ -80,6 +82,12 @@ StageTimer::~StageTimer()
 }
 
 // ---------------------------------------------------------------------------- context
+// Fixed scratch for the entry point that allocates nothing (ssdbox_match_encode_static): one
+// array per GPU, part of the loaded code object, held until the process ends.  Every context of
+// a device gets the same address, so calls that overlap on one GPU race on it.
+constexpr size_t kStaticScratchBytes = (size_t)SSDBOX_STATIC_SCRATCH_BYTES;
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
 // A stream of the library's own: non-blocking, at the highest priority the device offers
 // (several batches in flight on high-priority streams measured 9 % faster than on default ones).
 static hipError_t create_own_stream(hipStream_t *stream)
@@ -103,8 +111,18 @@ extern "C" int ssdbox_ctx_create(int device, void *stream, int own_stream, ssdbo
         set_error("libssdbox is built for gfx950 only; device %d is %s", device, prop.gcnArchName);
         return SSDBOX_ERR_UNSUPPORTED;
     }
-    ssdbox_ctx *ctx = new ssdbox_ctx();
+    // The array's name is a host-side stand-in; its address on this device comes from the
+    // runtime (the guard above made the device current).
+    void *scratch_ptr = nullptr;
+    SSD_CHECK_HIP(hipGetSymbolAddress(&scratch_ptr, HIP_SYMBOL(scratch)));
+    ssdbox_ctx *ctx = new (std::nothrow) ssdbox_ctx();
+    if (ctx == nullptr) {
+        set_error("ssdbox_ctx_create: out of host memory");
+        return SSDBOX_ERR_NOMEM;
+    }
     ctx->device = device;
+    ctx->static_scratch = static_cast<unsigned char *>(scratch_ptr);
+    ctx->static_scratch_bytes = kStaticScratchBytes;
     ctx->owns_stream = (own_stream != 0);
     ctx->timing = false;
     if (ctx->owns_stream) {

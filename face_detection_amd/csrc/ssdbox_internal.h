@@ -111,6 +111,11 @@ struct ssdbox_ctx {
     unsigned long long *mask;      // (batch, LIMIT, LIMIT/64) suppression bits
     size_t det_cap;                // images
     int *selftest_out;
+
+    // This device's copy of the library's fixed scratch array (ssdbox_ctx.hip), resolved when
+    // the context is created: what the entry point that allocates nothing works in.
+    unsigned char *static_scratch;
+    size_t static_scratch_bytes;
 };
 
 void set_error(const char *fmt, ...);

@@ -556,7 +556,7 @@ int match_common(ssdbox_ctx *ctx, const ssdbox_geom *geom, const float *d_anchor
                  int64_t num_anchors, const float *d_gt_boxes, const float *d_gt_labels,
                  const int32_t *d_gt_count, int batch, int gmax, float max_size,
                  float iou_threshold, float *d_conf, float *d_locs, float *d_y_true,
-                 int32_t *d_match_idx, float *d_match_iou)
+                 int32_t *d_match_idx, float *d_match_iou, bool static_scratch = false)
 {
     SSD_REQUIRE(ctx != nullptr, "match_encode: ctx is NULL");
     SSD_REQUIRE((geom != nullptr) != (d_anchors != nullptr),
@@ -583,23 +583,54 @@ int match_common(ssdbox_ctx *ctx, const ssdbox_geom *geom, const float *d_anchor
 
     DeviceGuard guard(ctx->device);
     const size_t need = (size_t)batch * (size_t)gmax;
-    int rc = ensure_buffer((void **)&ctx->gkey, &ctx->gkey_cap, need, sizeof(u64), true, ctx->stream);
-    if (rc != SSDBOX_OK) return rc;
-    if (ctx->gkey_dirty) {
-        SSD_CHECK_HIP(hipMemsetAsync(ctx->gkey, 0, ctx->gkey_cap * sizeof(u64), ctx->stream));
-        ctx->gkey_dirty = false;
-    }
-    if (geom != nullptr) {
-        rc = ensure_buffer((void **)&ctx->shape_tab, &ctx->shape_cap, need * (size_t)geom->host.k_total,
-                           sizeof(float4), false, ctx->stream);
+    u64 *s_gkey = nullptr;
+    float4 *s_shape = nullptr;
+    float *s_b0 = nullptr;
+    int *s_order = nullptr;
+    if (static_scratch) {
+        // Carve the call's scratch out of the device's fixed array: nothing is allocated.  The
+        // array keeps the previous call's contents, so the keys are cleared on every call.
+        SSD_REQUIRE(ctx->static_scratch != nullptr, "match_encode_static: the context has no fixed scratch");
+        const size_t kt = geom ? (size_t)geom->host.k_total : 0;
+        const size_t nb0 = geom ? (size_t)batch * (size_t)(geom->host.col_total + geom->host.rowk_total) : 0;
+        const size_t off_shape = need * sizeof(u64);
+        const size_t off_b0 = off_shape + need * kt * sizeof(float4);
+        const size_t off_order = (off_b0 + nb0 * sizeof(float) + 15) / 16 * 16;
+        const size_t total = off_order + (size_t)batch * sizeof(int);
+        if (total > ctx->static_scratch_bytes) {
+            set_error("match_encode_static: batch %d x gmax %d needs %zu bytes of scratch, the fixed array "
+                      "holds %zu (use ssdbox_match_encode)", batch, gmax, total, ctx->static_scratch_bytes);
+            return SSDBOX_ERR_INVALID;
+        }
+        unsigned char *base = ctx->static_scratch;
+        s_gkey = reinterpret_cast<u64 *>(base);
+        s_shape = reinterpret_cast<float4 *>(base + off_shape);
+        s_b0 = reinterpret_cast<float *>(base + off_b0);
+        s_order = reinterpret_cast<int *>(base + off_order);
+        SSD_CHECK_HIP(hipMemsetAsync(s_gkey, 0, need * sizeof(u64), ctx->stream));
+    } else {
+        int rc = ensure_buffer((void **)&ctx->gkey, &ctx->gkey_cap, need, sizeof(u64), true, ctx->stream);
         if (rc != SSDBOX_OK) return rc;
-        rc = ensure_buffer((void **)&ctx->b0_tab, &ctx->b0_cap,
-                           (size_t)batch * (size_t)(geom->host.col_total + geom->host.rowk_total),
-                           sizeof(float), false, ctx->stream);
-        if (rc != SSDBOX_OK) return rc;
-        rc = ensure_buffer((void **)&ctx->img_order, &ctx->order_cap, (size_t)batch, sizeof(int), false,
-                           ctx->stream);
-        if (rc != SSDBOX_OK) return rc;
+        if (ctx->gkey_dirty) {
+            SSD_CHECK_HIP(hipMemsetAsync(ctx->gkey, 0, ctx->gkey_cap * sizeof(u64), ctx->stream));
+            ctx->gkey_dirty = false;
+        }
+        if (geom != nullptr) {
+            rc = ensure_buffer((void **)&ctx->shape_tab, &ctx->shape_cap, need * (size_t)geom->host.k_total,
+                               sizeof(float4), false, ctx->stream);
+            if (rc != SSDBOX_OK) return rc;
+            rc = ensure_buffer((void **)&ctx->b0_tab, &ctx->b0_cap,
+                               (size_t)batch * (size_t)(geom->host.col_total + geom->host.rowk_total),
+                               sizeof(float), false, ctx->stream);
+            if (rc != SSDBOX_OK) return rc;
+            rc = ensure_buffer((void **)&ctx->img_order, &ctx->order_cap, (size_t)batch, sizeof(int), false,
+                               ctx->stream);
+            if (rc != SSDBOX_OK) return rc;
+        }
+        s_gkey = ctx->gkey;
+        s_shape = ctx->shape_tab;
+        s_b0 = ctx->b0_tab;
+        s_order = ctx->img_order;
     }
 
     MatchArgs args;
@@ -643,20 +674,26 @@ int match_common(ssdbox_ctx *ctx, const ssdbox_geom *geom, const float *d_anchor
     args.y_true = d_y_true;
     args.match_idx = d_match_idx;
     args.match_iou = d_match_iou;
-    args.gkey = ctx->gkey;
-    args.shape_tab = ctx->shape_tab;
-    args.b0_tab = ctx->b0_tab;
+    args.gkey = s_gkey;
+    args.shape_tab = s_shape;
+    args.b0_tab = s_b0;
     // ranking the images is quadratic in the batch: only where it is cheap
-    args.order = (geom != nullptr && batch > 1 && batch <= 4096) ? ctx->img_order : nullptr;
+    args.order = (geom != nullptr && batch > 1 && batch <= 4096) ? s_order : nullptr;
 
-    ctx->gkey_dirty = true;    // cleared again only when every launch was enqueued
+    // Event timing takes events from a pool that may have to grow: not on the path that
+    // allocates nothing.
+    const bool timing = ctx->timing;
+    if (static_scratch) ctx->timing = false;
+    else ctx->gkey_dirty = true;    // cleared again only when every launch was enqueued
+    int rc;
     if (geom != nullptr)
         rc = d_y_true ? launch_match<true, true>(ctx, args, batch, (int)n_tiles)
                       : launch_match<true, false>(ctx, args, batch, (int)n_tiles);
     else
         rc = d_y_true ? launch_match<false, true>(ctx, args, batch, (int)n_tiles)
                       : launch_match<false, false>(ctx, args, batch, (int)n_tiles);
-    if (rc == SSDBOX_OK) ctx->gkey_dirty = false;
+    ctx->timing = timing;
+    if (rc == SSDBOX_OK && !static_scratch) ctx->gkey_dirty = false;
     return rc;
 }
 
@@ -683,4 +720,18 @@ extern "C" int ssdbox_match_encode_ytrue(ssdbox_ctx *ctx, const ssdbox_geom *geo
     return match_common(ctx, geom, d_anchors, num_anchors, d_gt_boxes, d_gt_labels, d_gt_count,
                         batch, gmax, max_size, iou_threshold, nullptr, nullptr, d_y_true, nullptr,
                         nullptr);
+}
+
+// ssdbox_match_encode for callers that cannot allocate (HIP graph capture, serving loops): the
+// same kernels, their scratch carved out of the device's fixed array instead of buffers the
+// context grows.  No hipMalloc / hipFree and no host allocation on this path.
+extern "C" int ssdbox_match_encode_static(ssdbox_ctx *ctx, const ssdbox_geom *geom, const float *d_anchors,
+                                          int64_t num_anchors, const float *d_gt_boxes,
+                                          const float *d_gt_labels, const int32_t *d_gt_count, int batch,
+                                          int gmax, float max_size, float iou_threshold, float *d_conf,
+                                          float *d_locs, int32_t *d_match_idx, float *d_match_iou)
+{
+    return match_common(ctx, geom, d_anchors, num_anchors, d_gt_boxes, d_gt_labels, d_gt_count,
+                        batch, gmax, max_size, iou_threshold, d_conf, d_locs, nullptr, d_match_idx,
+                        d_match_iou, true);
 }

@@ -34,6 +34,7 @@ extern "C" {
 #define SSDBOX_MAX_BOXES_PER_CELL 16   /* boxes per feature-map cell                        */
 #define SSDBOX_MAX_NMS_LIMIT    1024   /* largest effective pre-NMS top-k, min(limit, N)    */
 #define SSDBOX_MAX_GT           4096   /* largest ground-truth count per image              */
+#define SSDBOX_STATIC_SCRATCH_BYTES (4u << 20) /* fixed per-GPU scratch of ssdbox_match_encode_static */
 
 typedef struct ssdbox_ctx ssdbox_ctx;
 typedef struct ssdbox_geom ssdbox_geom;
@@ -105,6 +106,22 @@ int ssdbox_match_encode(ssdbox_ctx *ctx, const ssdbox_geom *geom, const float *d
                         const float *d_gt_labels, const int32_t *d_gt_count, int batch,
                         int gmax, float max_size, float iou_threshold, float *d_conf,
                         float *d_locs, int32_t *d_match_idx, float *d_match_iou);
+
+/* ssdbox_match_encode without any allocation.  No counterpart in the reference: it exists for
+ * callers that cannot allocate device memory (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  Same arguments, same results; the kernels' scratch
+ * (per-box best-anchor keys and the per-image encode tables) lives in a fixed array of
+ * SSDBOX_STATIC_SCRATCH_BYTES that every GPU the library runs on holds until the process ends.
+ * A call whose scratch does not fit (roughly batch * gmax * (8 + 16 * box shapes of the
+ * geometry) bytes plus batch * 4 * (anchor columns + rows * shapes); batch 32 x gmax 256 at
+ * 640x640 takes 1.9 MB) returns SSDBOX_ERR_INVALID.  All calls on one GPU share the array:
+ * calls that overlap on one GPU (other streams, other contexts, other threads) race, so
+ * serialise them.  Stage timing (ssdbox_ctx_set_timing) is not recorded for this call. */
+int ssdbox_match_encode_static(ssdbox_ctx *ctx, const ssdbox_geom *geom, const float *d_anchors,
+                               int64_t num_anchors, const float *d_gt_boxes,
+                               const float *d_gt_labels, const int32_t *d_gt_count, int batch,
+                               int gmax, float max_size, float iou_threshold, float *d_conf,
+                               float *d_locs, int32_t *d_match_idx, float *d_match_iou);
 
 /* Same match, emitting the training-side consumer layout of utils/datasets.py:155-159
  * directly: d_y_true (batch,A,6) = [one_hot(int(conf), 2), locs]. */

@@ -1,0 +1,81 @@
+"""The entry point that allocates nothing (ssdbox_match_encode_static, scratch in the library's
+fixed per-GPU array) against ssdbox_match_encode, called through the C ABI: every output
+bit-identical, on two calls in a row of which the second is smaller, and sizes beyond the
+fixed array are rejected."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from conftest import ssd_config
+from face_detection_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _run(lib, fn, ctx, geom, A, boxes, labels, counts, size):
+    import torch
+    B, G = boxes.shape[0], boxes.shape[1]
+    dev = boxes.device
+    conf = torch.full((B, A), -7.0, dtype=torch.float32, device=dev)
+    locs = torch.full((B, A, 4), -7.0, dtype=torch.float32, device=dev)
+    midx = torch.full((B, A), -7, dtype=torch.int32, device=dev)
+    miou = torch.full((B, A), -7.0, dtype=torch.float32, device=dev)
+    rc = fn(ctx.handle, geom.handle, None, A, _p(boxes), _p(labels), _p(counts), B, G, float(size), 0.5,
+            _p(conf), _p(locs), _p(midx), _p(miou))
+    assert rc == 0, lib.ssdbox_last_error()
+    ctx.synchronize()
+    return [t.cpu().numpy() for t in (conf, locs, midx, miou)]
+
+
+def test_static_scratch_entry_equals_allocating_entry():
+    import torch
+    from face_detection_amd import _lib
+    from face_detection_amd.runtime import Context, geometry_for
+    lib = _lib.load()
+    torch.cuda.set_device(0)
+    ctx = Context(0)
+    # first a batch of 640x640 images with up to 64 boxes, then a smaller one (fewer images,
+    # fewer boxes, smaller geometry): the array still holds the first call's contents
+    for size, batch, gmax, seed in ((640, 8, 64, 3), (256, 3, 16, 4)):
+        cfg = ssd_config(size)
+        geom = geometry_for(cfg, 0)
+        A = geom.num_anchors
+        rng = np.random.default_rng(seed)
+        boxes, labels, counts = S.make_ground_truth(rng, batch, size, gmax=gmax)
+        labels[:, ::3] = 2.0                                  # labels are gathered, not assumed 1
+        d = [torch.from_numpy(x).cuda() for x in (boxes, labels, counts)]
+        want = _run(lib, lib.ssdbox_match_encode, ctx, geom, A, *d, size)
+        got = _run(lib, lib.ssdbox_match_encode_static, ctx, geom, A, *d, size)
+        for w, g in zip(want, got):
+            assert w.dtype == g.dtype and w.shape == g.shape
+            assert np.array_equal(w.view(np.uint32), g.view(np.uint32))
+        assert (want[0] > 0).any() and not (want[2] == -7).any()
+    # the same call twice in a row gives the same result (what must start at zero is cleared)
+    again = _run(lib, lib.ssdbox_match_encode_static, ctx, geom, A, *d, size)
+    for w, g in zip(want, again):
+        assert np.array_equal(w.view(np.uint32), g.view(np.uint32))
+
+
+def test_static_scratch_entry_rejects_what_does_not_fit():
+    import torch
+    from face_detection_amd import _lib
+    from face_detection_amd.runtime import Context, geometry_for
+    lib = _lib.load()
+    torch.cuda.set_device(0)
+    ctx = Context(0)
+    size, batch, gmax = 640, 64, 1024                        # 64 * 1024 * 200 B of tables
+    geom = geometry_for(ssd_config(size), 0)
+    A = geom.num_anchors
+    boxes = torch.zeros((batch, gmax, 4), dtype=torch.float32, device="cuda")
+    labels = torch.ones((batch, gmax), dtype=torch.float32, device="cuda")
+    counts = torch.ones((batch,), dtype=torch.int32, device="cuda")
+    conf = torch.empty((1,), dtype=torch.float32, device="cuda")   # never written: the call is refused
+    rc = lib.ssdbox_match_encode_static(ctx.handle, geom.handle, None, A, _p(boxes), _p(labels), _p(counts),
+                                        batch, gmax, float(size), 0.5, _p(conf), _p(conf), None, None)
+    assert rc == _lib.ERR_INVALID
+    assert b"fixed array" in lib.ssdbox_last_error()

@@ -121,6 +121,7 @@ extern "C" int ssdbox_ctx_create(int device, void *stream, int own_stream, ssdbo
         return SSDBOX_ERR_NOMEM;
     }
     ctx->device = device;
+    ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     ctx->static_scratch = static_cast<unsigned char *>(scratch_ptr);
     ctx->static_scratch_bytes = kStaticScratchBytes;
     ctx->owns_stream = (own_stream != 0);

@@ -21,6 +21,8 @@
 //      compacted in rank order into the detection rows.
 #include <string.h>
 
+#include <algorithm>
+
 #include "ssdbox_internal.h"
 
 namespace {
@@ -51,40 +53,67 @@ SSD_DEV float softmax_face(float l0, float l1)
 // Head rows are 24 bytes [bg, face, tx, ty, tw, th]; read as a float4 stream, the face score
 // of anchor 2q sits in .y of float4 3q and that of anchor 2q+1 in .w of float4 3q+1.  A wave
 // owns 384 consecutive float4 (256 anchors): six fully coalesced 1-KiB loads.
+// The grid is persistent: at most kSelWgsPerCu workgroups per CU, every wave walking the
+// (image, segment) items with a grid stride while the loads of its next item are in flight.
+// Half of the CU's wave slots stay free, so the per-image kernels of other streams' batches
+// (large workgroups) find room next to this one; long-lived waves with twelve loads per lane
+// in flight read at the same rate as a full grid does.
+constexpr int kSelWgsPerCu = 4;
+
 template <bool LOGITS>
 __global__ __launch_bounds__(kSelBlock) void select_rows6_kernel(const float4 *__restrict__ y, int n,
                                                                  float thr, u64 *__restrict__ cand,
-                                                                 int *__restrict__ seg_count, int nseg)
+                                                                 int *__restrict__ seg_count, int nseg,
+                                                                 int n_items, unsigned nseg_magic)
 {
     const int lane = threadIdx.x & 63;
-    const int seg = blockIdx.x * (kSelBlock / 64) + (threadIdx.x >> 6);
-    if (seg >= nseg) return;
-    const int img = blockIdx.y;
+    const int stride = (int)gridDim.x * (kSelBlock / 64);
+    int item = blockIdx.x * (kSelBlock / 64) + (threadIdx.x >> 6);
+    if (item >= n_items) return;
     const unsigned nf = (unsigned)n / 2u * 3u;
-    const float4 *src = y + (long long)img * nf;
-    const unsigned f0 = (unsigned)seg * 384u + (unsigned)lane;
-    float4 v[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        const unsigned f = f0 + 64u * k;
-        v[k] = (f < nf) ? src[f] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    u64 *out = cand + ((long long)img * nseg + seg) * kSeg;
     const u64 lt = (1ull << lane) - 1ull;
-    int off = 0;
+
+    auto fetch = [&](int it, float4 (&v)[6]) {
+        const int img = udiv_magic(it, nseg, nseg_magic);
+        const int seg = it - img * nseg;
+        const float4 *src = y + (long long)img * nf;
+        const unsigned f0 = (unsigned)seg * 384u + (unsigned)lane;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        const unsigned f = f0 + 64u * k;
-        const unsigned q = __umulhi(f, 0xAAAAAAABu) >> 1;      // f / 3
-        const unsigned r = f - 3u * q;
-        const float s1 = (r == 0u) ? v[k].y : v[k].w;
-        const float score = LOGITS ? softmax_face((r == 0u) ? v[k].x : v[k].z, s1) : s1;
-        const bool pass = (f < nf) && (r != 2u) && (score > thr);   // strict >, NaN fails
-        const u64 bal = __ballot(pass);
-        if (pass) out[off + __popcll(bal & lt)] = rank_key(score, 2u * q + r);
-        off += __popcll(bal);
+        for (int k = 0; k < 6; ++k) {
+            const unsigned f = f0 + 64u * k;
+            v[k] = (f < nf) ? src[f] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+
+    float4 v[6];
+    fetch(item, v);
+    while (true) {
+        const int next = item + stride;
+        float4 vn[6];
+        if (next < n_items) fetch(next, vn);
+        const int img = udiv_magic(item, nseg, nseg_magic);
+        const int seg = item - img * nseg;
+        const unsigned f0 = (unsigned)seg * 384u + (unsigned)lane;
+        u64 *out = cand + (long long)item * kSeg;
+        int off = 0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const unsigned f = f0 + 64u * k;
+            const unsigned q = __umulhi(f, 0xAAAAAAABu) >> 1;      // f / 3
+            const unsigned r = f - 3u * q;
+            const float s1 = (r == 0u) ? v[k].y : v[k].w;
+            const float score = LOGITS ? softmax_face((r == 0u) ? v[k].x : v[k].z, s1) : s1;
+            const bool pass = (f < nf) && (r != 2u) && (score > thr);   // strict >, NaN fails
+            const u64 bal = __ballot(pass);
+            if (pass) out[off + __popcll(bal & lt)] = rank_key(score, 2u * q + r);
+            off += __popcll(bal);
+        }
+        if (lane == 0) seg_count[item] = off;
+        if (next >= n_items) break;
+        item = next;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) v[k] = vn[k];
     }
-    if (lane == 0) seg_count[(long long)img * nseg + seg] = off;
 }
 
 // Any score layout (element stride / offset), optional threshold: used for caller-supplied
@@ -870,14 +899,20 @@ int run_detect(ssdbox_ctx *ctx, const ScoreLayout &sl, long long n, int batch, f
     if (rc != SSDBOX_OK) return rc;
     {
         dim3 grid((unsigned)((nseg + kSelBlock / 64 - 1) / (kSelBlock / 64)), batch);
-        if (sl.rows6 && sl.logits) {
-            launch_stage(ctx, SSDBOX_STAGE_SELECT, select_rows6_kernel<true>, grid, dim3(kSelBlock),
+        const long long n_items = (long long)nseg * batch;
+        // (the item -> image division by multiply-high is exact while items * segments < 2^32)
+        const bool rows6 = sl.rows6 && n_items < (1ll << 31) / kSeg && n_items * nseg < (1ll << 32);
+        const unsigned pgrid = (unsigned)std::min<long long>((n_items + kSelBlock / 64 - 1) / (kSelBlock / 64),
+                                                             (long long)ctx->num_cus * kSelWgsPerCu);
+        const unsigned nseg_magic = nseg > 1 ? (unsigned)(((1ull << 32) + (unsigned)nseg - 1) / (unsigned)nseg) : 0u;
+        if (rows6 && sl.logits) {
+            launch_stage(ctx, SSDBOX_STAGE_SELECT, select_rows6_kernel<true>, dim3(pgrid), dim3(kSelBlock),
                          reinterpret_cast<const float4 *>(sl.scores), (int)n, sl.thr, ctx->cand,
-                         ctx->cand_count, nseg);
-        } else if (sl.rows6) {
-            launch_stage(ctx, SSDBOX_STAGE_SELECT, select_rows6_kernel<false>, grid, dim3(kSelBlock),
+                         ctx->cand_count, nseg, (int)n_items, nseg_magic);
+        } else if (rows6) {
+            launch_stage(ctx, SSDBOX_STAGE_SELECT, select_rows6_kernel<false>, dim3(pgrid), dim3(kSelBlock),
                          reinterpret_cast<const float4 *>(sl.scores), (int)n, sl.thr, ctx->cand,
-                         ctx->cand_count, nseg);
+                         ctx->cand_count, nseg, (int)n_items, nseg_magic);
         } else {
             launch_stage(ctx, SSDBOX_STAGE_SELECT, select_strided_kernel, grid, dim3(kSelBlock),
                          sl.scores, sl.img_stride, sl.elem_stride, sl.elem_off, (int)n, sl.thr,

@@ -69,6 +69,7 @@ struct TimingRecord {
 
 struct ssdbox_ctx {
     int device;
+    int num_cus;                   // compute units of the device (sizes the persistent grids)
     hipStream_t stream;
     bool owns_stream;
     bool timing;

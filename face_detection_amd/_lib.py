@@ -22,6 +22,7 @@ STAGE_NAMES = ("match", "force", "select", "topk", "nms_mask", "nms_scan", "elem
 MAX_NMS_LIMIT = 1024
 MAX_GT = 4096
 MAX_LAYERS = 8
+STATIC_SCRATCH_BYTES = 4 << 20
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int

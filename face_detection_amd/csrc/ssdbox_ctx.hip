@@ -150,7 +150,7 @@ extern "C" int ssdbox_ctx_destroy(ssdbox_ctx *ctx)
         (void)hipEventDestroy(r.stop);
     }
     for (auto &e : ctx->event_pool) (void)hipEventDestroy(e);
-    void *bufs[] = {ctx->gkey, ctx->shape_tab, ctx->b0_tab, ctx->img_order, ctx->loss_key, ctx->loss_small, ctx->cand, ctx->cand_count, ctx->cand_hist, ctx->sboxes, ctx->sscores,
+    void *bufs[] = {ctx->gkey, ctx->loss_key, ctx->loss_small, ctx->cand, ctx->cand_count, ctx->cand_hist, ctx->sboxes, ctx->sscores,
                     ctx->sidx, ctx->keff, ctx->mask, ctx->selftest_out};
     for (void *b : bufs)
         if (b != nullptr) (void)hipFree(b);

@@ -81,16 +81,6 @@ struct ssdbox_ctx {
     unsigned long long *gkey;
     size_t gkey_cap;               // entries
     bool gkey_dirty;
-    // match scratch: box centre and log-size offsets of every (image, GT box, box shape) triple
-    float4 *shape_tab;
-    size_t shape_cap;
-    // match scratch: offsets of every anchor column (x) and (row, shape) pair (y) against
-    // box 0 of each image
-    float *b0_tab;
-    size_t b0_cap;
-    // match scratch: images ordered by falling box count
-    int *img_order;
-    size_t order_cap;
 
     // loss scratch: rank keys of the negative log-losses; histograms, state, sums, chunk counts
     unsigned *loss_key;

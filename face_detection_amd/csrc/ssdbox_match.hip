@@ -2,36 +2,36 @@
 // encoding for a whole batch (reference utils/box_utils.py:47-98, called per image from
 // utils/datasets.py:152).
 //
-// Kernel 0 (prep_kernel, geometry mode): everything in the encoding that does not depend on
-// the single anchor, once per image instead of once per anchor --
-//   * the box centre and log(box size / anchor size) / 0.2 for every (ground-truth box, anchor
-//     shape) pair, one 16-byte entry: what an anchor matched to that box gathers;
-//   * the x offset against box 0 for every anchor column and the y offset against box 0 for
-//     every (feature-map row, anchor shape) pair: anchors that overlap nothing match box 0,
-//     and that is most of them.
-// The match kernel then needs no logarithm and, for the anchors matched to box 0, no division.
+// Kernel 1 (match_geom_kernel, anchors from a geometry).  A workgroup owns a tile of one feature
+// map, 32 anchor columns wide and several groups of 2*R rows tall; its four waves take the
+// groups in turn (lanes 0-31 / 32-63 hold two neighbouring rows, a lane owns R rows of one anchor
+// column, so the x overlap with a box is computed once for its rows).  R = 4 on fine maps, R = 1
+// on coarse maps, whose big anchors overlap most boxes.
+//   Prologue, one round trip to memory: the image's boxes and labels, the lane's anchor column,
+// the tile's row centres.  Ground-truth boxes whose bounding box cannot touch the tile are
+// dropped by a ballot compaction into LDS: their IoU with every anchor of the tile is exactly
+// +0, which can neither become a first maximum (the running best starts at +0 / box 0) nor a
+// best anchor of that box (a zero key leaves the default "anchor 0").  Then everything of
+// encode (utils/box_utils.py:115-123) that does not depend on the single anchor goes into LDS
+// tables: log(box size / shape size) / 0.2 for every (listed box, anchor shape) pair and for
+// box 0, and the y offset against box 0 for every (row, shape) pair; the x offset against box 0
+// is one division per lane.  Anchors that overlap nothing match box 0, and that is most of them:
+// they need no division and no logarithm.
+//   Main loop: a wave's groups read LDS only and issue the stores of their rows, so a wave never
+// waits for memory between its prologue and its exit and one prologue is spread over many rows.
+// The best anchor of each box is a wave-level maximum, folded through LDS and then global memory
+// as a packed 64-bit (IoU bits, ~anchor index) atomic max, so ties resolve to the lowest anchor.
+//   More than 256 boxes per image: the list is built 256 boxes at a time, every wave has one
+// group, its running best lives in registers across the chunks and the final encode gathers the
+// matched box from memory.
 //
-// Kernel 1 (match_kernel).  With a geometry a workgroup owns a tile of one feature map, 32
-// anchor columns wide, and each of its four waves a band of 2*R rows of it (lanes 0-31 /
-// 32-63 take two neighbouring rows, a lane owns R rows of one anchor column, so the x overlap
-// with a box is computed once for its rows); anchors are built from the centre tables.
-// R = 4 on fine maps; R = 1 on coarse maps, whose big anchors overlap most boxes (the walk
-// over the tile's box list then costs a quarter per box, and these tiles get the lowest
-// block indices so that the longest ones start first).  The tables are padded by a tile per
-// layer, so rows and columns past the edge read (and never store) without clamping, and
-// every row of a lane is reached from a per-wave scalar base plus one per-lane offset.
-// With a materialised anchor array a workgroup owns 256 consecutive anchors.
-// Ground-truth boxes whose bounding box cannot touch the tile are dropped by a ballot
-// compaction into LDS, 256 boxes at a time: their IoU with every anchor of the tile is
-// exactly +0, which can neither become a first maximum (the running best starts at +0 /
-// index 0) nor a best anchor of that box (a zero key leaves the default "anchor 0").  The
-// best anchor of each box is a wave-level maximum, folded through LDS and then global memory
-// as a packed 64-bit (IoU bits, ~anchor index) atomic max, so ties resolve to the lowest
-// anchor index.
+// Kernel 1' (match_array_kernel, materialised anchor array): a workgroup owns 256 consecutive
+// anchors, same culling, encode from the gathered box.
 //
 // Kernel 2 (force_kernel): per image, the forced scatter of utils/box_utils.py:72-87 in
 // ascending ground-truth order (the highest box index wins a shared anchor), rewriting the
 // <= G affected anchors, and clearing the keys for the next call.
+#include <stdlib.h>
 #include <string.h>
 
 #include "ssdbox_internal.h"
@@ -40,19 +40,26 @@ namespace {
 
 typedef unsigned long long u64;
 
-// What the match kernel reads of one layer: sixteen dwords, fetched as one scalar load.
+constexpr int kListCap = kBlock;       // ground-truth boxes examined (and at most listed) per chunk
+
+// What the geometry kernel reads of one layer: sixteen dwords, fetched as one scalar load.
 struct alignas(64) MatchLayer {
     int fm_h, row_anchors, n_box, anchor_base;
     int tiles_x, tile_base;
     unsigned tilesx_magic, nbox_magic;
-    int col_off, rowk_off, cy_off, k_off;
+    int col_off, cy_off;
+    int n_groups;                  // groups of 2*R rows per tile
+    int coarse;                    // R = 1 instead of 4
     float half_wmax, half_hmax;
-    int coarse, pad_;
+    int pad_[2];
 };
 
 struct MatchArgs {
     MatchLayer ml[SSDBOX_MAX_LAYERS];
-    GeomDev geom;                  // by value: layer constants arrive with the kernel arguments
+    int n_layers;
+    int nbox_max;                  // largest n_box of the geometry: row length of the LDS tables
+    int rows_max;                  // largest tile height in rows
+    const GeomDev *geom;           // device copy of the geometry (force kernel)
     const float4 *col_tab;         // geometry: cx, w, h of every anchor column (padded)
     const float *cx_tab;
     const float *cy_tab;
@@ -71,18 +78,17 @@ struct MatchArgs {
     int *match_idx;
     float *match_iou;
     u64 *gkey;
-    float4 *shape_tab;             // (batch, gmax, geom.k_total), see prep_kernel
-    float *b0_tab;                 // (batch, geom.col_total + geom.rowk_total), see prep_kernel
-    int *order;                    // (batch) images by falling box count, see prep_kernel; or NULL
 };
 
 struct MatchShared {
-    float4 box[kBlock];            // compacted ground-truth list of the current chunk
-    float area[kBlock];
-    int gidx[kBlock];
-    u64 key[kBlock];               // best (IoU, ~anchor) of each listed box within this tile
+    float4 box[kListCap];          // compacted ground-truth list of the current chunk
+    float area[kListCap];
+    float label[kListCap];
+    int gidx[kListCap];
+    u64 key[kListCap];             // best (IoU, ~anchor) of each listed box within this tile
     int wcnt[2][kBlock / 64];
     float ext[4][kBlock / 64];
+    float4 lane_const[kBlock];     // per thread: what only the final encode of a row needs
 };
 
 // Loads and stores at a wave-uniform base plus a 32-bit per-lane byte offset: one address
@@ -95,18 +101,13 @@ SSD_DEV T ld_off(const void *base, unsigned byte_off)
 // The targets are written once and not read again by this library: nontemporal stores keep
 // them from lingering as dirty lines in the L2s (match+encode of a batch measured 18 % faster
 // with several batches in flight, the kernel alone 6 %).
-#ifndef SSD_NT_STORES
-#define SSD_NT_STORES 1
-#endif
 typedef float vf2 __attribute__((ext_vector_type(2)));
 typedef float vf4 __attribute__((ext_vector_type(4)));
 template <typename T>
 SSD_DEV void st_off(void *base, unsigned byte_off, T v)
 {
     char *q = static_cast<char *>(base) + byte_off;
-    if constexpr (!SSD_NT_STORES) {
-        *reinterpret_cast<T *>(q) = v;
-    } else if constexpr (sizeof(T) == 16) {
+    if constexpr (sizeof(T) == 16) {
         __builtin_nontemporal_store(__builtin_bit_cast(vf4, v), reinterpret_cast<vf4 *>(q));
     } else if constexpr (sizeof(T) == 8) {
         __builtin_nontemporal_store(__builtin_bit_cast(vf2, v), reinterpret_cast<vf2 *>(q));
@@ -138,379 +139,455 @@ SSD_DEV void store_target(const MatchArgs &p, long long row, unsigned off, float
     }
 }
 
-// Layer of entry `s` of a table whose per-layer offsets grow with the layer.
-template <typename F>
-SSD_DEV int layer_of(const GeomDev &g, int s, F offset_of)
+// Ballot compaction of the chunk's boxes that may touch the extent [ex0, ex1] x [ey0, ey1] into
+// the LDS list (dropped only when provably disjoint; NaN is kept).  Returns the list length
+// (uniform).  Two barriers; `par` alternates the counter buffer between calls.
+SSD_DEV int build_list(MatchShared &sm, int par, unsigned t, unsigned lane, int wave, int g, bool in_range,
+                       float4 b, float lab, float ex0, float ey0, float ex1, float ey1, float max_size)
 {
-    int m = 0;
+    const bool keep = in_range && !(b.z <= ex0) && !(b.x >= ex1) && !(b.w <= ey0) && !(b.y >= ey1);
+    const u64 bal = __ballot(keep);
+    if (lane == 0) sm.wcnt[par][wave] = __popcll(bal);
+    __syncthreads();
+    int off = __popcll(bal & ((1ull << lane) - 1ull));
+    int n_list = 0;
 #pragma unroll
-    for (int l = 1; l < SSDBOX_MAX_LAYERS; ++l) m += (l < g.n_layers && s >= offset_of(g.layer[l])) ? 1 : 0;
-    return m;
+    for (int w = 0; w < kBlock / 64; ++w) {
+        const int c = sm.wcnt[par][w];
+        if (w < wave) off += c;
+        n_list += c;
+    }
+    if (n_list == 0) return 0;          // nothing near this tile (the usual case on fine maps)
+    if (keep) {
+        sm.box[off] = b;
+        sm.area[off] = clip0(b.z - b.x, max_size) * clip0(b.w - b.y, max_size);
+        sm.label[off] = lab;
+        sm.gidx[off] = g;
+    }
+    if ((int)t < n_list) sm.key[t] = 0ull;
+    __syncthreads();
+    return n_list;
 }
 
-// encode (utils/box_utils.py:115-123) split by what each term depends on; the operations on
-// each value are those of encode_one, so the bits are too.
-__global__ __launch_bounds__(kBlock) void prep_kernel(const MatchArgs p)
+// The walk of R rows of one anchor column over the listed boxes: compute_iou
+// (utils/box_utils.py:35-42), running best per row (first maximum wins, :66-67) and the best
+// anchor of every box within the tile (:70).  `sel` receives the list position (LISTPOS) or the
+// ground-truth index of the best box.  Boxes outside the rows' y extent [wy0, wy1] are dropped 64
+// at a time (a lane per box); of the others the next ones' box, area and key are on their way
+// from LDS while the current ones are evaluated.  With one row per lane two boxes are evaluated
+// per step, so that their divisions overlap as those of the rows do otherwise.  Returns whether
+// any box reached the IoU evaluation.
+template <int R, bool LISTPOS>
+SSD_DEV bool walk_list(MatchShared &sm, int n_list, unsigned lane, float max_size, float ax0, float ax1,
+                       const float (&ay0)[R], const float (&ay1)[R], const float (&a_area)[R], float wy0,
+                       float wy1, int a0, int a_step, float (&best)[R], int (&sel)[R])
 {
-    const int img = blockIdx.y;
-    const GeomDev &g = p.geom;
-    // The match kernel's workgroups start in grid order, image by image: images with many boxes
-    // go first, so that the long tiles are not the last ones running (a fifth of the kernel
-    // time between the best and the worst order of the bench batch).
-    if (p.order != nullptr && blockIdx.x == 0) {
-        __shared__ int s_rank;
-        if (threadIdx.x == 0) s_rank = 0;
-        __syncthreads();
-        const int mine = p.gt_count[img];
-        int before = 0;
-        for (int b = threadIdx.x; b < p.batch; b += kBlock) {
-            const int c = p.gt_count[b];
-            before += (c > mine || (c == mine && b < img)) ? 1 : 0;
+    constexpr int U = (R == 1) ? 2 : 1;        // boxes per step
+    bool touched = false;
+    for (int base = 0; base < n_list; base += 64) {
+        const float4 mine = sm.box[min(base + (int)lane, n_list - 1)];
+        u64 todo = __ballot(base + (int)lane < n_list && !(mine.w <= wy0) && !(mine.y >= wy1));
+        if (todo == 0ull) continue;
+        int qn[U];
+        float4 gb_next[U];
+        float area_next[U];
+        u64 key_next[U];
+        auto fetch = [&]() {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                // a step short of boxes repeats its last one: evaluated twice, same result
+                if (todo != 0ull) {
+                    qn[u] = base + __builtin_ctzll(todo);
+                    todo &= todo - 1ull;
+                } else {
+                    qn[u] = qn[u > 0 ? u - 1 : 0];
+                }
+                gb_next[u] = sm.box[qn[u]];
+                area_next[u] = sm.area[qn[u]];
+                key_next[u] = sm.key[qn[u]];
+            }
+        };
+        fetch();
+        bool more = true;
+        while (more) {
+            int qc[U];
+            float4 gb[U];
+            float garea[U], cur[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                qc[u] = qn[u];
+                gb[u] = gb_next[u];
+                garea[u] = area_next[u];
+                cur[u] = u2f((uint32_t)(key_next[u] >> 32));   // may be stale: it only filters
+            }
+            more = todo != 0ull;
+            if (more) fetch();
+            // the x overlap is shared by the rows
+            float iw[U];
+            bool any = false;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                iw[u] = vmin(ax1, gb[u].z) - vmax(ax0, gb[u].x);
+                any = any || iw[u] > 0.0f;
+            }
+            // no lane of the wave can overlap these boxes: every IoU is +0, nothing to update
+            if (__ballot(any) == 0ull) continue;
+            touched = true;
+            // Evaluated without branches (an IoU of a non-overlapping pair is replaced by +0
+            // afterwards) so that the divisions overlap.
+            float iou[U][R];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float cw = vmin(iw[u], max_size);
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    const float ih = vmin(ay1[i], gb[u].w) - vmax(ay0[i], gb[u].y);
+                    const float inter = cw * vmin(ih, max_size);
+                    const float uni = (a_area[i] + garea[u]) - inter;
+                    const float q_iou = inter / uni;
+                    iou[u][i] = (iw[u] > 0.0f && ih > 0.0f) ? q_iou : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (u > 0 && qc[u] == qc[u - 1]) continue;     // the repeated box of a short step
+                const int gsel = LISTPOS ? qc[u] : sm.gidx[qc[u]];
+                float v = 0.0f;        // this lane's best IoU with the box, and its lowest row there
+                int vi = 0;
+#pragma unroll
+                for (int i = R - 1; i >= 0; --i) {
+                    if (iou[u][i] > best[i]) {
+                        best[i] = iou[u][i];
+                        sel[i] = gsel;
+                    }
+                    if (iou[u][i] >= v) {
+                        v = iou[u][i];
+                        vi = i;
+                    }
+                }
+                // argmax over anchors (:70): only a lane at or above the tile's best IoU so far
+                // for this box can change it; wave maximum, then the lowest anchor holding it
+                if (__ballot(v > 0.0f && v >= cur[u]) != 0ull) {
+                    const float mx = wave_max_nonneg(v);
+                    const int av = a0 + vi * a_step;
+                    const int a_src = (int)wave_min_u32((v == mx) ? (uint32_t)av : 0xFFFFFFFFu);
+                    if (lane == 0) {
+                        const u64 key = ((u64)f2u(mx) << 32) | (u64)(0xFFFFFFFFu - (uint32_t)a_src);
+                        if (key > sm.key[qc[u]]) atomicMax(&sm.key[qc[u]], key);
+                    }
+                }
+            }
         }
-        if (before != 0) atomicAdd(&s_rank, before);
-        __syncthreads();
-        if (threadIdx.x == 0) p.order[s_rank] = img;
     }
-    const int n_b0 = g.col_total + g.rowk_total;
-    const int u = blockIdx.x * kBlock + threadIdx.x;
-    const float4 *gt = p.gt_boxes + (long long)img * p.gmax;
-    if (u < n_b0) {
-        const float4 b0 = gt[0];
-        float v;
-        if (u < g.col_total) {
-            const float4 c = p.col_tab[u];
-            v = ((b0.x + b0.z) / 2.0f - c.x) / (c.y * 0.1f);
-        } else {
-            const int s = u - g.col_total;
-            const int m = layer_of(g, s, [](const LayerDev &L) { return L.rowk_off; });
-            const LayerDev &L = g.layer[m];
-            const int r = s - L.rowk_off;
-            const int row = udiv_magic(r, L.n_box, L.nbox_magic);    // may lie in the padding
-            const int k = r - row * L.n_box;
-            v = ((b0.y + b0.w) / 2.0f - p.cy_tab[L.cy_off + row]) / (L.bh[k] * 0.1f);
-        }
-        p.b0_tab[(long long)img * n_b0 + u] = v;
-        return;
-    }
-    const int kt = g.k_total;
-    const int G = max(min(p.gt_count[img], p.gmax), 1);
-    const int w = u - n_b0;
-    if (w >= G * kt) return;
-    const int gi = w / kt;
-    const int s = w - gi * kt;
-    const int m = layer_of(g, s, [](const LayerDev &L) { return L.k_off; });
-    const int k = s - g.layer[m].k_off;
-    const float4 b = gt[gi];
-    p.shape_tab[((long long)img * p.gmax + gi) * kt + s] =
-        make_float4((b.x + b.z) / 2.0f, (b.y + b.w) / 2.0f,
-                    ssd_logf((b.z - b.x) / g.layer[m].bw[k]) / 0.2f,
-                    ssd_logf((b.w - b.y) / g.layer[m].bh[k]) / 0.2f);
+    return touched;
 }
 
-// R anchors (rows of one anchor column) per thread; a tile is 8*R rows x 32 anchor columns.
-template <bool GEOM, bool YTRUE, bool DETAILS, int R>
-SSD_DEV void match_tile(const MatchArgs &p, MatchShared &sm, int m)
+// The tile's best anchor of every listed box joins the image-wide best in global memory.
+SSD_DEV void flush_keys(MatchShared &sm, int n_list, unsigned t, u64 *gkey)
+{
+    __syncthreads();
+    if ((int)t < n_list) {
+        const u64 key = sm.key[t];
+        if (key != 0ull) atomicMax(&gkey[sm.gidx[t]], key);
+    }
+}
+
+extern __shared__ __align__(16) unsigned char match_dyn_lds[];
+
+// MULTI: the image may hold more than kListCap boxes (one group per wave, see the file comment).
+template <bool YTRUE, bool DETAILS, bool MULTI, int R>
+SSD_DEV void geom_tile(const MatchArgs &p, MatchShared &sm, const MatchLayer &L)
 {
     const unsigned t = threadIdx.x;
     const unsigned lane = t & 63u;
     const int wave = __builtin_amdgcn_readfirstlane((int)(t >> 6));
-    const int tile = blockIdx.x;
-    const int img = (GEOM && p.order != nullptr) ? p.order[blockIdx.y] : (int)blockIdx.y;
+    const int img = blockIdx.y;
     const float4 *gt = p.gt_boxes + (long long)img * p.gmax;
-    u64 *gkey = p.gkey + (long long)img * p.gmax;
     const float *labels = p.gt_labels + (long long)img * p.gmax;
-    const float4 *shapes = p.shape_tab + (long long)img * p.gmax * p.geom.k_total;
+    u64 *gkey = p.gkey + (long long)img * p.gmax;
+    const unsigned n_box = (unsigned)L.n_box;
 
-    // The count and the first 256 boxes are fetched together with everything else the
-    // prologue reads, so a tile pays one memory round trip before it can start.
+    // LDS tables: log-size offsets per (listed box | box 0 in slot kListCap, shape), row centres,
+    // y offsets against box 0 per (row, shape)
+    float2 *s_lwh = reinterpret_cast<float2 *>(match_dyn_lds);
+    float *s_cy = reinterpret_cast<float *>(s_lwh + (kListCap + 1) * p.nbox_max);
+    float *s_ty0 = s_cy + p.rows_max;
+
+    // ---- prologue: everything this workgroup reads from memory, requested together
     const int G = max(min(p.gt_count[img], p.gmax), 1);
-    const float4 b_first = ld_off<float4>(gt, min(t, (unsigned)p.gmax - 1u) * 16u);
+    const unsigned g_first = min(t, (unsigned)p.gmax - 1u);
+    const float4 b_first = ld_off<float4>(gt, g_first * 16u);
+    const float l_first = ld_off<float>(labels, g_first * 4u);
+    const float4 b0 = gt[0];
+    const float label0 = labels[0];
 
-    bool valid[R];
-    float acy[R], ay0[R], ay1[R], a_area[R];
-    float ty0[R];                  // y offset against box 0
-    float acx, aw, ah, ax0, ax1;
-    float ex0, ey0, ex1, ey1;      // bounding box of every anchor of this workgroup
-    float wy0 = -3.0e38f, wy1 = 3.0e38f;   // y extent of this wave's anchors (geometry mode)
-    float tx0 = 0.0f;              // x offset against box 0
-    float2 twh0 = make_float2(0.0f, 0.0f);
-    unsigned shape = 0;            // the lane's anchor shape among the shapes of all layers
-    int a0;                        // index of the lane's first anchor; row i adds i * a_step
-    int a_step = 0;
-    long long out_row = 0;         // output row of the wave's first anchor; row i adds i * a_step
-    unsigned out_off;              // the lane's rows from there
+    const int tt = (int)blockIdx.x - L.tile_base;
+    const int ty = udiv_magic(tt, L.tiles_x, L.tilesx_magic);
+    const int tx = tt - ty * L.tiles_x;
+    const int tile_rows = L.n_groups * 2 * R;
+    const int t_r0 = ty * tile_rows;                          // first row of the tile
+    const int rows_here = min(tile_rows, L.fm_h - t_r0);      // >= 1
+    const unsigned c0 = (unsigned)tx * kTileCols;
+    const unsigned c = c0 + (lane & 31u);                     // may lie in the padding
+    const unsigned k = n_box == 1u ? 0u : c - __umulhi(c, L.nbox_magic) * n_box;
+    const float4 *cols = p.col_tab + L.col_off;               // padded by a tile per layer
+    const float4 col = ld_off<float4>(cols, c * 16u);
+    // the layer's box shapes are the (w, h) of its first n_box anchor columns
+    const unsigned k_item = n_box == 1u ? 0u : t - __umulhi(t, L.nbox_magic) * n_box;
+    const float4 shape_item = ld_off<float4>(cols, k_item * 16u);
+    float cy_mine = 0.0f;
+    if ((int)t < tile_rows) cy_mine = p.cy_tab[L.cy_off + min(t_r0 + (int)t, L.fm_h - 1)];
+    const float acx = col.x, aw = col.y, ah = col.z;
+    const bool col_ok = c < (unsigned)L.row_anchors;
+    const unsigned rowslot = lane >> 5;
 
-    if (GEOM) {
-        const MatchLayer L = p.ml[m];
-        const int tt = tile - L.tile_base;
-        const int ty = udiv_magic(tt, L.tiles_x, L.tilesx_magic);
-        const int tx = tt - ty * L.tiles_x;
-        const int t_r0 = ty * (8 * R);                   // first row of the tile
-        const int r0 = t_r0 + 2 * R * wave;              // first row of this wave
-        const float *b0 = p.b0_tab + (long long)img * (p.geom.col_total + p.geom.rowk_total);
-        const unsigned c0 = (unsigned)tx * kTileCols;
-        const unsigned c = c0 + (lane & 31u);            // may lie in the padding
-        const unsigned k = L.n_box == 1 ? 0u : c - __umulhi(c, L.nbox_magic) * (unsigned)L.n_box;
-        const unsigned ci = (unsigned)L.col_off + c;
-        const float4 col = ld_off<float4>(p.col_tab, ci * 16u);
-        acx = col.x;
-        aw = col.y;
-        ah = col.z;
-        tx0 = ld_off<float>(b0, ci * 4u);
-        shape = (unsigned)L.k_off + k;
-        twh0 = ld_off<float2>(shapes, shape * 16u + 8u);
-        const unsigned rowslot = lane >> 5;
-        const bool col_ok = c < (unsigned)L.row_anchors;
-        // a wave whose band starts below the map reads the padding of the last rows only
-        const int r0c = min(r0, L.fm_h);
-        const float *cy = p.cy_tab + L.cy_off + r0c;
-        const float *ty_tab = b0 + p.geom.col_total + L.rowk_off + r0c * L.n_box;
-        const unsigned ty_off = (rowslot * (unsigned)L.n_box + k) * 4u;
-#pragma unroll
-        for (int i = 0; i < R; ++i) {
-            valid[i] = col_ok && r0 + (int)rowslot + 2 * i < L.fm_h;
-            acy[i] = ld_off<float>(cy + 2 * i, rowslot * 4u);
-            ty0[i] = ld_off<float>(ty_tab + 2 * i * L.n_box, ty_off);
-        }
-        out_off = rowslot * (unsigned)L.row_anchors + c;
-        a_step = 2 * L.row_anchors;
-        a0 = L.anchor_base + r0 * L.row_anchors + (int)out_off;
-        out_row = (long long)img * p.num_anchors + L.anchor_base + r0 * L.row_anchors;
-        // Corner rounding is monotonic, so the first/last centre with the widest box bound
-        // every corner of the tile (and of the wave's band).
-        const int t_r1 = min(t_r0 + 8 * R, L.fm_h) - 1;
-        const int w_r0 = min(r0, L.fm_h - 1);
-        const int w_r1 = min(r0 + 2 * R, L.fm_h) - 1;
-        const int c1 = min((int)c0 + kTileCols, L.row_anchors) - 1;
-        ex0 = p.col_tab[L.col_off + (int)c0].x - L.half_wmax;
-        ex1 = p.col_tab[L.col_off + c1].x + L.half_wmax;
-        ey0 = p.cy_tab[L.cy_off + t_r0] - L.half_hmax;
-        ey1 = p.cy_tab[L.cy_off + t_r1] + L.half_hmax;
-        wy0 = p.cy_tab[L.cy_off + w_r0] - L.half_hmax;
-        wy1 = p.cy_tab[L.cy_off + max(w_r1, w_r0)] + L.half_hmax;
-    } else {
-        const int a_first = tile * kBlock + wave * 64;
-        const int last = p.num_anchors - 1;
-        valid[0] = a_first + (int)lane < p.num_anchors;
-        a0 = min(a_first + (int)lane, last);
-        const int base = min(a_first, last);             // a wave past the end stores nothing
-        out_off = (unsigned)(a0 - base);
-        out_row = (long long)img * p.num_anchors + base;
-        const float4 anc = ld_off<float4>(p.anchors + base, out_off * 16u);
-        acx = anc.x;
-        acy[0] = anc.y;
-        aw = anc.z;
-        ah = anc.w;
-    }
+    // Corner rounding is monotonic, so the first/last centre with the widest box bound every
+    // corner of the tile.
+    const float ex0 = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(acx), 0)) - L.half_wmax;
+    const float ex1 = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(acx), 31)) + L.half_wmax;
+    const float ey0 = p.cy_tab[L.cy_off + t_r0] - L.half_hmax;
+    const float ey1 = p.cy_tab[L.cy_off + t_r0 + rows_here - 1] + L.half_hmax;
 
     const float ahw = aw / 2.0f, ahh = ah / 2.0f;
-    if (!GEOM) {
-        float lo_x = acx - ahw, lo_y = acy[0] - ahh, hi_x = acx + ahw, hi_y = acy[0] + ahh;
-        for (int o = 32; o > 0; o >>= 1) {
-            lo_x = fminf(lo_x, __shfl_xor(lo_x, o));
-            lo_y = fminf(lo_y, __shfl_xor(lo_y, o));
-            hi_x = fmaxf(hi_x, __shfl_xor(hi_x, o));
-            hi_y = fmaxf(hi_y, __shfl_xor(hi_y, o));
-        }
-        if (lane == 0) {
-            sm.ext[0][wave] = lo_x;
-            sm.ext[1][wave] = lo_y;
-            sm.ext[2][wave] = hi_x;
-            sm.ext[3][wave] = hi_y;
-        }
-        __syncthreads();
-        ex0 = fminf(fminf(sm.ext[0][0], sm.ext[0][1]), fminf(sm.ext[0][2], sm.ext[0][3]));
-        ey0 = fminf(fminf(sm.ext[1][0], sm.ext[1][1]), fminf(sm.ext[1][2], sm.ext[1][3]));
-        ex1 = fmaxf(fmaxf(sm.ext[2][0], sm.ext[2][1]), fmaxf(sm.ext[2][2], sm.ext[2][3]));
-        ey1 = fmaxf(fmaxf(sm.ext[3][0], sm.ext[3][1]), fmaxf(sm.ext[3][2], sm.ext[3][3]));
-    }
- 
-    float best[R];         // reduce_max / argmax over GT, first maximum wins (:66-67)
-    int bidx[R];
-#pragma unroll
-    for (int i = 0; i < R; ++i) {
-        best[i] = 0.0f;
-        bidx[i] = 0;
+    const float ax0 = acx - ahw, ax1 = acx + ahw;            // transform_center_to_corner, :177-179
+    const float a_w = clip0(ax1 - ax0, p.max_size);
+    if (!MULTI) {
+        // What only the final encode of a row needs waits in LDS (read back by the same thread),
+        // not in registers that would stay occupied during the walk over the boxes: the
+        // anchor's centre x, encode's divisors (:117-118) and the x offset against box 0.
+        const float awv = aw * 0.1f, ahv = ah * 0.1f;
+        sm.lane_const[t] = make_float4(acx, awv, ahv, ((b0.x + b0.z) / 2.0f - acx) / awv);
     }
 
-    bool touched = false;          // some box reached this wave's IoU evaluation
+    const int a_step = 2 * L.row_anchors;
+    const unsigned out_off = rowslot * (unsigned)L.row_anchors + c;
+    const int n_groups_here = (rows_here + 2 * R - 1) / (2 * R);
+
+    float best[R];                 // reduce_max / argmax over GT, first maximum wins (:66-67)
+    int sel[R];
+    bool touched = false;
+
     int par = 0;
-    for (int g0 = 0; g0 < G; g0 += kBlock, par ^= 1) {
+    for (int g0 = 0; g0 < G; g0 += kListCap, par ^= 1) {
         const int g = g0 + (int)t;
-        bool keep = false;
         float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+        float lab = 0.0f;
         if (g < G) {
             b = (g0 == 0) ? b_first : ld_off<float4>(gt, (unsigned)g * 16u);
-            // dropped only when provably disjoint from every anchor here (NaN is kept)
-            keep = !(b.z <= ex0) && !(b.x >= ex1) && !(b.w <= ey0) && !(b.y >= ey1);
+            lab = (g0 == 0) ? l_first : ld_off<float>(labels, (unsigned)g * 4u);
         }
-        const u64 bal = __ballot(keep);
-        if (lane == 0) sm.wcnt[par][wave] = __popcll(bal);
-        __syncthreads();
-        int off = __popcll(bal & ((1ull << lane) - 1ull));
-        int n_list = 0;
-#pragma unroll
-        for (int w = 0; w < kBlock / 64; ++w) {
-            const int c = sm.wcnt[par][w];
-            if (w < wave) off += c;
-            n_list += c;
-        }
-        if (n_list == 0) continue;      // nothing near this tile (the usual case on fine maps)
-        if (keep) {
-            sm.box[off] = b;
-            sm.area[off] = clip0(b.z - b.x, p.max_size) * clip0(b.w - b.y, p.max_size);
-            sm.gidx[off] = g;
-        }
-        if ((int)t < n_list) sm.key[t] = 0ull;
-        __syncthreads();
+        const int n_list = build_list(sm, par, t, lane, wave, g, g < G, b, lab, ex0, ey0, ex1, ey1, p.max_size);
 
-        // Corners and areas only where a box came near: most tiles of a fine map never get
-        // here.  transform_center_to_corner, utils/box_utils.py:177-179
-        ax0 = acx - ahw;
-        ax1 = acx + ahw;
-        const float a_w = clip0(ax1 - ax0, p.max_size);
-#pragma unroll
-        for (int i = 0; i < R; ++i) {
-            ay0[i] = acy[i] - ahh;
-            ay1[i] = acy[i] + ahh;
-            a_area[i] = a_w * clip0(ay1[i] - ay0[i], p.max_size);
-            // an anchor past the edge overlaps nothing (and is never stored)
-            if (!valid[i]) ay1[i] = -3.0e38f;
+        if (g0 == 0) {
+            if ((int)t < tile_rows) {
+                s_cy[t] = cy_mine;
+                if (!MULTI) {
+                    const float dy = (b0.y + b0.w) / 2.0f - cy_mine;
+#pragma unroll 1
+                    for (unsigned kk = 0; kk < n_box; ++kk) s_ty0[t * n_box + kk] = dy / (cols[kk].z * 0.1f);
+                }
+            }
         }
+        if (!MULTI) {
+            // log-size offsets of the listed boxes and of box 0, one (box, shape) item per thread
+            const unsigned n_items = (unsigned)(n_list + 1) * n_box;
+#pragma unroll 1
+            for (unsigned item = t; item < n_items; item += kBlock) {
+                const unsigned q = n_box == 1u ? item : __umulhi(item, L.nbox_magic);
+                const unsigned kk = item - q * n_box;
+                const float4 sh = (item == t) ? shape_item : cols[kk];
+                const float4 bx = (int)q < n_list ? sm.box[q] : b0;
+                const unsigned slot = (int)q < n_list ? q : (unsigned)kListCap;
+                s_lwh[slot * n_box + kk] =
+                    make_float2(ssd_logf((bx.z - bx.x) / sh.y) / 0.2f, ssd_logf((bx.w - bx.y) / sh.z) / 0.2f);
+            }
+        }
+        if (!MULTI || g0 == 0) __syncthreads();
 
-        float4 gb_next = sm.box[0];
-        for (int q = 0; q < n_list; ++q) {
-            // the next box is on its way from LDS while this one is evaluated
-            const float4 gb = gb_next;
-            gb_next = sm.box[min(q + 1, n_list - 1)];
-            // compute_iou, utils/box_utils.py:35-42; the x overlap is shared by the rows
-            const float iw = vmin(ax1, gb.z) - vmax(ax0, gb.x);
-            // no lane of the wave can overlap this box: every IoU is +0, nothing to update
-            if (__ballot(iw > 0.0f && !(gb.w <= wy0) && !(gb.y >= wy1)) == 0ull) continue;
-            touched = true;
-            // The rows are evaluated without branches (an IoU of a non-overlapping pair is
-            // replaced by +0 afterwards) so that their divisions overlap.
-            const float cw = vmin(iw, p.max_size);
-            const float garea = sm.area[q];
-            const int gidx = sm.gidx[q];
-            float iou[R];
+#pragma unroll 1
+        for (int gi = wave; gi < n_groups_here; gi += kBlock / 64) {
+            const int lr0 = gi * 2 * R;                       // the group's first row within the tile
+            if (!MULTI || g0 == 0) {
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    best[i] = 0.0f;
+                    sel[i] = 0;
+                }
+                if (!MULTI) touched = false;
+            }
+            bool valid[R];
+#pragma unroll
+            for (int i = 0; i < R; ++i) valid[i] = col_ok && lr0 + (int)rowslot + 2 * i < rows_here;
+            const long long out_row =
+                (long long)img * p.num_anchors + L.anchor_base + (long long)(t_r0 + lr0) * L.row_anchors;
+            if (n_list != 0) {
+                // Corners and areas only where a box came near.
+                float ay0[R], ay1[R], a_area[R];
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    const float acy = s_cy[min(lr0 + (int)rowslot + 2 * i, tile_rows - 1)];
+                    ay0[i] = acy - ahh;
+                    ay1[i] = acy + ahh;
+                    a_area[i] = a_w * clip0(ay1[i] - ay0[i], p.max_size);
+                    // an anchor past the edge overlaps nothing (and is never stored)
+                    if (!valid[i]) ay1[i] = -3.0e38f;
+                }
+                // y extent of the group's anchors
+                const float wy0 = s_cy[lr0] - L.half_hmax;
+                const float wy1 = s_cy[min(lr0 + 2 * R, rows_here) - 1] + L.half_hmax;
+                const int a0 = L.anchor_base + (t_r0 + lr0) * L.row_anchors + (int)out_off;
+                const bool hit = walk_list<R, !MULTI>(sm, n_list, lane, p.max_size, ax0, ax1, ay0, ay1, a_area,
+                                                      wy0, wy1, a0, a_step, best, sel);
+                touched = touched || hit;
+            }
+            if (MULTI && g0 + kListCap < G) continue;        // more boxes to come
+
+            if (MULTI) {
+                // gather labels / boxes, threshold, encode every anchor (:89-96)
+                float labv[R];
+                float4 gb[R];
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    labv[i] = ld_off<float>(labels, (unsigned)sel[i] * 4u);
+                    gb[i] = ld_off<float4>(gt, (unsigned)sel[i] * 16u);
+                }
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    const float acy = s_cy[min(lr0 + (int)rowslot + 2 * i, tile_rows - 1)];
+                    const float conf = (best[i] < p.thr) ? 0.0f : labv[i];
+                    const float4 tgt = encode_one(make_float4(acx, acy, aw, ah), gb[i], 0.1f, 0.2f);
+                    if (valid[i])
+                        store_target<YTRUE, DETAILS>(p, out_row + (long long)i * a_step, out_off, conf, tgt, sel[i],
+                                                     best[i]);
+                }
+                continue;
+            }
+
+            // Offsets against box 0: what every anchor that overlaps nothing gets.  Row by row,
+            // stored at once: nothing below waits for memory.
+            const float2 twh0 = s_lwh[(unsigned)kListCap * n_box + k];
+            unsigned t_opaque = t;         // the compiler must not forward the stored registers
+            asm volatile("" : "+v"(t_opaque));
+            const float4 lc = sm.lane_const[t_opaque];                    // acx, awv, ahv, tx0
 #pragma unroll
             for (int i = 0; i < R; ++i) {
-                const float ih = vmin(ay1[i], gb.w) - vmax(ay0[i], gb.y);
-                const float inter = cw * vmin(ih, p.max_size);
-                const float uni = (a_area[i] + garea) - inter;
-                const float q_iou = inter / uni;
-                iou[i] = (iw > 0.0f && ih > 0.0f) ? q_iou : 0.0f;
-                if (iou[i] > best[i]) {
-                    best[i] = iou[i];
-                    bidx[i] = gidx;
+                const int lr = min(lr0 + (int)rowslot + 2 * i, tile_rows - 1);
+                float conf = (0.0f < p.thr) ? 0.0f : label0;
+                float4 tgt = make_float4(lc.w, s_ty0[(unsigned)lr * n_box + k], twh0.x, twh0.y);
+                int idx = 0;
+                if (touched && __ballot(valid[i] && best[i] > 0.0f) != 0ull) {
+                    // gather labels / boxes, threshold, encode (:89-96), from the LDS list
+                    const unsigned q = (unsigned)sel[i];
+                    const float4 bx = sm.box[q];
+                    const float2 lwh = s_lwh[q * n_box + k];
+                    const float lq = sm.label[q];
+                    const int gq = sm.gidx[q];
+                    const float ex = ((bx.x + bx.z) / 2.0f - lc.x) / lc.y;
+                    const float ey = ((bx.y + bx.w) / 2.0f - s_cy[lr]) / lc.z;
+                    if (best[i] > 0.0f) {
+                        tgt = make_float4(ex, ey, lwh.x, lwh.y);
+                        conf = (best[i] < p.thr) ? 0.0f : lq;
+                        idx = gq;
+                    }
                 }
-            }
-            float v = iou[0];          // this lane's best IoU with the box
-#pragma unroll
-            for (int i = 1; i < R; ++i) v = fmaxf(v, iou[i]);
-            // Only a lane at or above the tile's best IoU so far for this box can change it.
-            const float cur = u2f((uint32_t)(sm.key[q] >> 32));
-            if (__ballot(v > 0.0f && v >= cur) != 0ull) {
-                // argmax over anchors (:70): wave maximum, then the lowest anchor holding it
-                // (within a lane: its lowest row)
-                int vi = 0;
-#pragma unroll
-                for (int i = R - 1; i > 0; --i)
-                    if (iou[i] == v) vi = i;
-                if (iou[0] == v) vi = 0;
-                const float mx = wave_max_nonneg(v);
-                const int av = a0 + vi * a_step;
-                const int a_src = (int)wave_min_u32((v == mx) ? (uint32_t)av : 0xFFFFFFFFu);
-                if (lane == 0) {
-                    const u64 key = ((u64)f2u(mx) << 32) | (u64)(0xFFFFFFFFu - (uint32_t)a_src);
-                    if (key > sm.key[q]) atomicMax(&sm.key[q], key);
-                }
+                if (valid[i])
+                    store_target<YTRUE, DETAILS>(p, out_row + (long long)i * a_step, out_off, conf, tgt, idx, best[i]);
             }
         }
-        __syncthreads();
-        if ((int)t < n_list) {
-            const u64 key = sm.key[t];
-            if (key != 0ull) atomicMax(&gkey[sm.gidx[t]], key);
-        }
-        __syncthreads();
-    }
-
-    // No box came near and the threshold is positive: every anchor of the wave matches box 0
-    // with IoU +0 and is a negative; its offsets are the table values.
-    if (GEOM && !touched && 0.0f < p.thr) {
-#pragma unroll
-        for (int i = 0; i < R; ++i) {
-            if (valid[i])
-                store_target<YTRUE, DETAILS>(p, out_row + (long long)i * a_step, out_off, 0.0f,
-                                             make_float4(tx0, ty0[i], twh0.x, twh0.y), 0, 0.0f);
-        }
-        return;
-    }
-
-    // gather labels / boxes, threshold, encode every anchor (:89-96).  Loads and stores share
-    // one in-order counter per wave, so all the gathers go first and the stores last: a store
-    // between two gathers would make the second one wait for the store to reach memory.
-    // The decisions below are per wave and row (not per lane), which keeps the loads of all
-    // rows in flight together.
-    float lab[R];
-    float4 gb[R];                  // the matched box (anchor array) / its table entry (geometry)
-    bool far[R];                   // some lane of the wave matched row i to a box other than 0
-#pragma unroll
-    for (int i = 0; i < R; ++i) {
-        lab[i] = 0.0f;
-        if (__ballot(valid[i] && !(best[i] < p.thr)) != 0ull) lab[i] = ld_off<float>(labels, (unsigned)bidx[i] * 4u);
-        far[i] = !GEOM || __ballot(valid[i] && bidx[i] != 0) != 0ull;
-        if (far[i]) {
-            gb[i] = GEOM ? ld_off<float4>(shapes, ((unsigned)bidx[i] * (unsigned)p.geom.k_total + shape) * 16u)
-                         : ld_off<float4>(gt, (unsigned)bidx[i] * 16u);
-        }
-    }
-    float conf[R];
-    float4 tgt[R];
-#pragma unroll
-    for (int i = 0; i < R; ++i) {
-        conf[i] = (best[i] < p.thr) ? 0.0f : lab[i];
-        if (GEOM) {
-            tgt[i] = make_float4(tx0, ty0[i], twh0.x, twh0.y);
-            if (far[i]) {
-                const float4 e = make_float4((gb[i].x - acx) / (aw * 0.1f), (gb[i].y - acy[i]) / (ah * 0.1f),
-                                             gb[i].z, gb[i].w);
-                if (bidx[i] != 0) tgt[i] = e;
-            }
-        } else {
-            tgt[i] = encode_one(make_float4(acx, acy[i], aw, ah), gb[i], 0.1f, 0.2f);
-        }
-    }
-    // every value is final (and every gather has landed) before the first store is issued
-#pragma unroll
-    for (int i = 0; i < R; ++i)
-        asm volatile("" : "+v"(conf[i]), "+v"(tgt[i].x), "+v"(tgt[i].y), "+v"(tgt[i].z), "+v"(tgt[i].w));
-#pragma unroll
-    for (int i = 0; i < R; ++i) {
-        if (valid[i])
-            store_target<YTRUE, DETAILS>(p, out_row + (long long)i * a_step, out_off, conf[i], tgt[i], bidx[i],
-                                         best[i]);
+        if (n_list != 0) flush_keys(sm, n_list, t, gkey);
+        if (g0 + kListCap < G) __syncthreads();
     }
 }
 
-template <bool GEOM, bool YTRUE, bool DETAILS>
-__global__ __launch_bounds__(kBlock) void match_kernel(const MatchArgs p)
+template <bool YTRUE, bool DETAILS, bool MULTI>
+__global__ __launch_bounds__(kBlock, 5) void match_geom_kernel(const MatchArgs p)
 {
     __shared__ MatchShared sm;
-    if (GEOM) {
-        const int tile = blockIdx.x;
-        int m = 0;                         // tile ranges run from the last layer to the first
+    const int tile = blockIdx.x;
+    int m = 0;                             // tile ranges run from the last layer to the first
 #pragma unroll
-        for (int l = 0; l + 1 < SSDBOX_MAX_LAYERS; ++l)
-            m += (l + 1 < p.geom.n_layers && tile < p.ml[l].tile_base) ? 1 : 0;
-        if (p.ml[m].coarse)
-            match_tile<true, YTRUE, DETAILS, 1>(p, sm, m);
-        else
-            match_tile<true, YTRUE, DETAILS, kRowsPerThread>(p, sm, m);
-    } else {
-        match_tile<false, YTRUE, DETAILS, 1>(p, sm, 0);
+    for (int l = 0; l + 1 < SSDBOX_MAX_LAYERS; ++l) m += (l + 1 < p.n_layers && tile < p.ml[l].tile_base) ? 1 : 0;
+    const MatchLayer L = p.ml[m];
+    if (L.coarse)
+        geom_tile<YTRUE, DETAILS, MULTI, 1>(p, sm, L);
+    else
+        geom_tile<YTRUE, DETAILS, MULTI, kRowsPerThread>(p, sm, L);
+}
+
+// Materialised anchor array: a workgroup owns 256 consecutive anchors, one per thread.
+template <bool YTRUE, bool DETAILS>
+__global__ __launch_bounds__(kBlock) void match_array_kernel(const MatchArgs p)
+{
+    __shared__ MatchShared sm;
+    const unsigned t = threadIdx.x;
+    const unsigned lane = t & 63u;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(t >> 6));
+    const int img = blockIdx.y;
+    const float4 *gt = p.gt_boxes + (long long)img * p.gmax;
+    const float *labels = p.gt_labels + (long long)img * p.gmax;
+    u64 *gkey = p.gkey + (long long)img * p.gmax;
+
+    const int G = max(min(p.gt_count[img], p.gmax), 1);
+    const float4 b_first = ld_off<float4>(gt, min(t, (unsigned)p.gmax - 1u) * 16u);
+    const float l_first = ld_off<float>(labels, min(t, (unsigned)p.gmax - 1u) * 4u);
+
+    const int a_first = (int)blockIdx.x * kBlock + wave * 64;
+    const int last = p.num_anchors - 1;
+    const bool valid = a_first + (int)lane < p.num_anchors;
+    const int a0 = min(a_first + (int)lane, last);
+    const int base = min(a_first, last);                 // a wave past the end stores nothing
+    const unsigned out_off = (unsigned)(a0 - base);
+    const long long out_row = (long long)img * p.num_anchors + base;
+    const float4 anc = ld_off<float4>(p.anchors + base, out_off * 16u);
+    const float ahw = anc.z / 2.0f, ahh = anc.w / 2.0f;
+    const float ax0 = anc.x - ahw, ax1 = anc.x + ahw;
+
+    float lo_x = ax0, lo_y = anc.y - ahh, hi_x = ax1, hi_y = anc.y + ahh;
+    for (int o = 32; o > 0; o >>= 1) {
+        lo_x = fminf(lo_x, __shfl_xor(lo_x, o));
+        lo_y = fminf(lo_y, __shfl_xor(lo_y, o));
+        hi_x = fmaxf(hi_x, __shfl_xor(hi_x, o));
+        hi_y = fmaxf(hi_y, __shfl_xor(hi_y, o));
     }
+    if (lane == 0) {
+        sm.ext[0][wave] = lo_x;
+        sm.ext[1][wave] = lo_y;
+        sm.ext[2][wave] = hi_x;
+        sm.ext[3][wave] = hi_y;
+    }
+    __syncthreads();
+    const float ex0 = fminf(fminf(sm.ext[0][0], sm.ext[0][1]), fminf(sm.ext[0][2], sm.ext[0][3]));
+    const float ey0 = fminf(fminf(sm.ext[1][0], sm.ext[1][1]), fminf(sm.ext[1][2], sm.ext[1][3]));
+    const float ex1 = fmaxf(fmaxf(sm.ext[2][0], sm.ext[2][1]), fmaxf(sm.ext[2][2], sm.ext[2][3]));
+    const float ey1 = fmaxf(fmaxf(sm.ext[3][0], sm.ext[3][1]), fmaxf(sm.ext[3][2], sm.ext[3][3]));
+
+    float ay0[1] = {anc.y - ahh}, ay1[1] = {anc.y + ahh};
+    float a_area[1] = {clip0(ax1 - ax0, p.max_size) * clip0(ay1[0] - ay0[0], p.max_size)};
+    if (!valid) ay1[0] = -3.0e38f;
+    float best[1] = {0.0f};
+    int sel[1] = {0};
+    int par = 0;
+    for (int g0 = 0; g0 < G; g0 += kListCap, par ^= 1) {
+        const int g = g0 + (int)t;
+        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+        float lab = 0.0f;
+        if (g < G) {
+            b = (g0 == 0) ? b_first : ld_off<float4>(gt, (unsigned)g * 16u);
+            lab = (g0 == 0) ? l_first : ld_off<float>(labels, (unsigned)g * 4u);
+        }
+        const int n_list = build_list(sm, par, t, lane, wave, g, g < G, b, lab, ex0, ey0, ex1, ey1, p.max_size);
+        if (n_list == 0) continue;
+        walk_list<1, false>(sm, n_list, lane, p.max_size, ax0, ax1, ay0, ay1, a_area, -3.0e38f, 3.0e38f, a0, 0,
+                            best, sel);
+        flush_keys(sm, n_list, t, gkey);
+        __syncthreads();
+    }
+    // gather labels / boxes, threshold, encode every anchor (:89-96)
+    const float labv = ld_off<float>(labels, (unsigned)sel[0] * 4u);
+    const float4 gb = ld_off<float4>(gt, (unsigned)sel[0] * 16u);
+    const float conf = (best[0] < p.thr) ? 0.0f : labv;
+    const float4 tgt = encode_one(anc, gb, 0.1f, 0.2f);
+    if (valid) store_target<YTRUE, DETAILS>(p, out_row, out_off, conf, tgt, sel[0], best[0]);
 }
 
 template <bool GEOM, bool YTRUE>
@@ -550,23 +627,40 @@ __global__ __launch_bounds__(kBlock) void force_kernel(const MatchArgs p)
 }
 
 template <bool GEOM, bool YTRUE>
-int launch_match(ssdbox_ctx *ctx, const MatchArgs &args, int batch, int n_tiles)
+int launch_match(ssdbox_ctx *ctx, const MatchArgs &args, int batch, int n_tiles, size_t lds_bytes)
 {
-    if (GEOM) {
-        const int items = args.geom.col_total + args.geom.rowk_total + args.gmax * args.geom.k_total;
-        launch_stage(ctx, SSDBOX_STAGE_SHAPES, prep_kernel, dim3((items + kBlock - 1) / kBlock, batch),
-                     dim3(kBlock), args);
-    }
-    SSD_CHECK_HIP(hipGetLastError());
     const dim3 grid(n_tiles, batch);
-    if (args.match_idx != nullptr || args.match_iou != nullptr)
-        launch_stage(ctx, SSDBOX_STAGE_MATCH, match_kernel<GEOM, YTRUE, true>, grid, dim3(kBlock), args);
+    const bool details = args.match_idx != nullptr || args.match_iou != nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    const bool timed = ctx->timing && acquire_events(ctx, ev);
+    void (*kernel)(const MatchArgs);
+    if (!GEOM)
+        kernel = details ? match_array_kernel<YTRUE, true> : match_array_kernel<YTRUE, false>;
+    else if (args.gmax > kListCap)
+        kernel = details ? match_geom_kernel<YTRUE, true, true> : match_geom_kernel<YTRUE, false, true>;
     else
-        launch_stage(ctx, SSDBOX_STAGE_MATCH, match_kernel<GEOM, YTRUE, false>, grid, dim3(kBlock), args);
+        kernel = details ? match_geom_kernel<YTRUE, true, false> : match_geom_kernel<YTRUE, false, false>;
+    hipExtLaunchKernelGGL(kernel, grid, dim3(kBlock), (unsigned)lds_bytes, ctx->stream, ev[0], ev[1], 0u, args);
+    if (timed) ctx->records.push_back({SSDBOX_STAGE_MATCH, ev[0], ev[1]});
     SSD_CHECK_HIP(hipGetLastError());
     launch_stage(ctx, SSDBOX_STAGE_FORCE, force_kernel<GEOM, YTRUE>, dim3(batch), dim3(kBlock), args);
     SSD_CHECK_HIP(hipGetLastError());
     return SSDBOX_OK;
+}
+
+// Groups of rows a wave of a fine-map tile takes in turn (tile height = 4 waves x this x 8 rows).
+// More groups spread one prologue over more rows: with several batches in flight, 5 groups gave
+// 2.3e6 images/s for match+encode at batch 32 @640x640 against 2.0e6 with 2 and 1.7e6 with 1,
+// while the kernel alone on the chip takes 25 us against 22 us (fewer, longer workgroups).
+// SSDBOX_MATCH_GROUPS overrides the choice for experiments.
+int groups_per_wave()
+{
+    static const int v = [] {
+        const char *e = getenv("SSDBOX_MATCH_GROUPS");
+        const int n = e ? atoi(e) : 0;
+        return (n >= 1 && n <= 8) ? n : 5;
+    }();
+    return v;
 }
 
 int match_common(ssdbox_ctx *ctx, const ssdbox_geom *geom, const float *d_anchors,
@@ -596,34 +690,21 @@ int match_common(ssdbox_ctx *ctx, const ssdbox_geom *geom, const float *d_anchor
     }
     SSD_REQUIRE(num_anchors >= 1 && num_anchors < (1ll << 28), "match_encode: num_anchors %lld",
                 (long long)num_anchors);
-    const long long n_tiles = geom ? geom->host.n_tiles : (num_anchors + kBlock - 1) / kBlock;
 
     DeviceGuard guard(ctx->device);
     const size_t need = (size_t)batch * (size_t)gmax;
     u64 *s_gkey = nullptr;
-    float4 *s_shape = nullptr;
-    float *s_b0 = nullptr;
-    int *s_order = nullptr;
     if (static_scratch) {
-        // Carve the call's scratch out of the device's fixed array: nothing is allocated.  The
+        // The call's scratch comes out of the device's fixed array: nothing is allocated.  The
         // array keeps the previous call's contents, so the keys are cleared on every call.
         SSD_REQUIRE(ctx->static_scratch != nullptr, "match_encode_static: the context has no fixed scratch");
-        const size_t kt = geom ? (size_t)geom->host.k_total : 0;
-        const size_t nb0 = geom ? (size_t)batch * (size_t)(geom->host.col_total + geom->host.rowk_total) : 0;
-        const size_t off_shape = need * sizeof(u64);
-        const size_t off_b0 = off_shape + need * kt * sizeof(float4);
-        const size_t off_order = (off_b0 + nb0 * sizeof(float) + 15) / 16 * 16;
-        const size_t total = off_order + (size_t)batch * sizeof(int);
-        if (total > ctx->static_scratch_bytes) {
+        if (need * sizeof(u64) > ctx->static_scratch_bytes) {
             set_error("match_encode_static: batch %d x gmax %d needs %zu bytes of scratch, the fixed array "
-                      "holds %zu (use ssdbox_match_encode)", batch, gmax, total, ctx->static_scratch_bytes);
+                      "holds %zu (use ssdbox_match_encode)", batch, gmax, need * sizeof(u64),
+                      ctx->static_scratch_bytes);
             return SSDBOX_ERR_INVALID;
         }
-        unsigned char *base = ctx->static_scratch;
-        s_gkey = reinterpret_cast<u64 *>(base);
-        s_shape = reinterpret_cast<float4 *>(base + off_shape);
-        s_b0 = reinterpret_cast<float *>(base + off_b0);
-        s_order = reinterpret_cast<int *>(base + off_order);
+        s_gkey = reinterpret_cast<u64 *>(ctx->static_scratch);
         SSD_CHECK_HIP(hipMemsetAsync(s_gkey, 0, need * sizeof(u64), ctx->stream));
     } else {
         int rc = ensure_buffer((void **)&ctx->gkey, &ctx->gkey_cap, need, sizeof(u64), true, ctx->stream);
@@ -632,48 +713,62 @@ int match_common(ssdbox_ctx *ctx, const ssdbox_geom *geom, const float *d_anchor
             SSD_CHECK_HIP(hipMemsetAsync(ctx->gkey, 0, ctx->gkey_cap * sizeof(u64), ctx->stream));
             ctx->gkey_dirty = false;
         }
-        if (geom != nullptr) {
-            rc = ensure_buffer((void **)&ctx->shape_tab, &ctx->shape_cap, need * (size_t)geom->host.k_total,
-                               sizeof(float4), false, ctx->stream);
-            if (rc != SSDBOX_OK) return rc;
-            rc = ensure_buffer((void **)&ctx->b0_tab, &ctx->b0_cap,
-                               (size_t)batch * (size_t)(geom->host.col_total + geom->host.rowk_total),
-                               sizeof(float), false, ctx->stream);
-            if (rc != SSDBOX_OK) return rc;
-            rc = ensure_buffer((void **)&ctx->img_order, &ctx->order_cap, (size_t)batch, sizeof(int), false,
-                               ctx->stream);
-            if (rc != SSDBOX_OK) return rc;
-        }
         s_gkey = ctx->gkey;
-        s_shape = ctx->shape_tab;
-        s_b0 = ctx->b0_tab;
-        s_order = ctx->img_order;
     }
 
     MatchArgs args;
     memset(&args, 0, sizeof(args));
+    long long n_tiles = (num_anchors + kBlock - 1) / kBlock;
+    size_t lds_bytes = 0;
     if (geom != nullptr) {
-        args.geom = geom->host;
-        for (int m = 0; m < geom->host.n_layers; ++m) {
-            const LayerDev &L = geom->host.layer[m];
+        // Tiling of this launch: fine maps get tall tiles whose waves take several groups of
+        // rows; coarse maps, and every map when an image may hold more boxes than one list,
+        // one group per wave.  Tiles are numbered from the last (coarsest) layer to the first:
+        // workgroups start in index order, and the coarse tiles carry the longest box lists.
+        const bool multi = gmax > kListCap;
+        const GeomDev &g = geom->host;
+        args.n_layers = g.n_layers;
+        for (int m = 0; m < g.n_layers; ++m) {
+            const LayerDev &L = g.layer[m];
             MatchLayer &M = args.ml[m];
+            const int rows_per_group = 2 * (L.coarse ? 1 : kRowsPerThread);
+            const int groups_total = (L.fm_h + rows_per_group - 1) / rows_per_group;
+            int n_groups = kBlock / 64;
+            if (!multi && !L.coarse) {
+                const int cap = (kBlock / 64) * groups_per_wave();
+                const int tiles_y = (groups_total + cap - 1) / cap;
+                n_groups = (groups_total + tiles_y - 1) / tiles_y;
+            }
+            const int tile_rows = n_groups * rows_per_group;
+            const int tiles_y = (L.fm_h + tile_rows - 1) / tile_rows;
             M.fm_h = L.fm_h;
             M.row_anchors = L.row_anchors;
             M.n_box = L.n_box;
             M.anchor_base = L.anchor_base;
             M.tiles_x = L.tiles_x;
-            M.tile_base = L.tile_base;
+            M.tile_base = tiles_y;                          // count for now, base below
             M.tilesx_magic = L.tilesx_magic;
             M.nbox_magic = L.nbox_magic;
             M.col_off = L.col_off;
-            M.rowk_off = L.rowk_off;
             M.cy_off = L.cy_off;
-            M.k_off = L.k_off;
+            M.n_groups = n_groups;
+            M.coarse = L.coarse;
             M.half_wmax = L.wmax / 2.0f;
             M.half_hmax = L.hmax / 2.0f;
-            M.coarse = L.coarse;
+            args.nbox_max = L.n_box > args.nbox_max ? L.n_box : args.nbox_max;
+            args.rows_max = tile_rows > args.rows_max ? tile_rows : args.rows_max;
         }
+        n_tiles = 0;
+        for (int m = g.n_layers - 1; m >= 0; --m) {
+            const long long count = (long long)args.ml[m].tiles_x * args.ml[m].tile_base;
+            args.ml[m].tile_base = (int)n_tiles;
+            n_tiles += count;
+        }
+        SSD_REQUIRE(args.rows_max <= kBlock, "match_encode: tile of %d rows", args.rows_max);
+        lds_bytes = (size_t)(kListCap + 1) * args.nbox_max * sizeof(float2) +
+                    (size_t)args.rows_max * (1 + args.nbox_max) * sizeof(float);
     }
+    args.geom = geom ? geom->d_geom : nullptr;
     args.col_tab = geom ? geom->d_col : nullptr;
     args.cx_tab = geom ? geom->d_cx : nullptr;
     args.cy_tab = geom ? geom->d_cy : nullptr;
@@ -692,10 +787,6 @@ int match_common(ssdbox_ctx *ctx, const ssdbox_geom *geom, const float *d_anchor
     args.match_idx = d_match_idx;
     args.match_iou = d_match_iou;
     args.gkey = s_gkey;
-    args.shape_tab = s_shape;
-    args.b0_tab = s_b0;
-    // ranking the images is quadratic in the batch: only where it is cheap
-    args.order = (geom != nullptr && batch > 1 && batch <= 4096) ? s_order : nullptr;
 
     // Event timing takes events from a pool that may have to grow: not on the path that
     // allocates nothing.
@@ -704,11 +795,11 @@ int match_common(ssdbox_ctx *ctx, const ssdbox_geom *geom, const float *d_anchor
     else ctx->gkey_dirty = true;    // cleared again only when every launch was enqueued
     int rc;
     if (geom != nullptr)
-        rc = d_y_true ? launch_match<true, true>(ctx, args, batch, (int)n_tiles)
-                      : launch_match<true, false>(ctx, args, batch, (int)n_tiles);
+        rc = d_y_true ? launch_match<true, true>(ctx, args, batch, (int)n_tiles, lds_bytes)
+                      : launch_match<true, false>(ctx, args, batch, (int)n_tiles, lds_bytes);
     else
-        rc = d_y_true ? launch_match<false, true>(ctx, args, batch, (int)n_tiles)
-                      : launch_match<false, false>(ctx, args, batch, (int)n_tiles);
+        rc = d_y_true ? launch_match<false, true>(ctx, args, batch, (int)n_tiles, 0)
+                      : launch_match<false, false>(ctx, args, batch, (int)n_tiles, 0);
     ctx->timing = timing;
     if (rc == SSDBOX_OK && !static_scratch) ctx->gkey_dirty = false;
     return rc;

@@ -110,13 +110,12 @@ int ssdbox_match_encode(ssdbox_ctx *ctx, const ssdbox_geom *geom, const float *d
 /* ssdbox_match_encode without any allocation.  No counterpart in the reference: it exists for
  * callers that cannot allocate device memory (code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc).  Same arguments, same results; the kernels' scratch
- * (per-box best-anchor keys and the per-image encode tables) lives in a fixed array of
+ * (one 8-byte best-anchor key per image and ground-truth slot) lives in a fixed array of
  * SSDBOX_STATIC_SCRATCH_BYTES that every GPU the library runs on holds until the process ends.
- * A call whose scratch does not fit (roughly batch * gmax * (8 + 16 * box shapes of the
- * geometry) bytes plus batch * 4 * (anchor columns + rows * shapes); batch 32 x gmax 256 at
- * 640x640 takes 1.9 MB) returns SSDBOX_ERR_INVALID.  All calls on one GPU share the array:
- * calls that overlap on one GPU (other streams, other contexts, other threads) race, so
- * serialise them.  Stage timing (ssdbox_ctx_set_timing) is not recorded for this call. */
+ * A call whose scratch does not fit (batch * gmax * 8 bytes; batch 32 x gmax 256 takes 64 KiB,
+ * the array holds batch * gmax up to 524 288) returns SSDBOX_ERR_INVALID.  All calls on one GPU
+ * share the array: calls that overlap on one GPU (other streams, other contexts, other threads)
+ * race, so serialise them.  Stage timing (ssdbox_ctx_set_timing) is not recorded for this call. */
 int ssdbox_match_encode_static(ssdbox_ctx *ctx, const ssdbox_geom *geom, const float *d_anchors,
                                int64_t num_anchors, const float *d_gt_boxes,
                                const float *d_gt_labels, const int32_t *d_gt_count, int batch,

@@ -39,9 +39,9 @@ def test_static_scratch_entry_equals_allocating_entry():
     lib = _lib.load()
     torch.cuda.set_device(0)
     ctx = Context(0)
-    # first a batch of 640x640 images with up to 64 boxes, then a smaller one (fewer images,
+    # first a batch of 640x640 images with up to 300 boxes (more than one list of 256), then a smaller one (fewer images,
     # fewer boxes, smaller geometry): the array still holds the first call's contents
-    for size, batch, gmax, seed in ((640, 8, 64, 3), (256, 3, 16, 4)):
+    for size, batch, gmax, seed in ((640, 8, 300, 3), (256, 3, 16, 4)):
         cfg = ssd_config(size)
         geom = geometry_for(cfg, 0)
         A = geom.num_anchors
@@ -68,14 +68,20 @@ def test_static_scratch_entry_rejects_what_does_not_fit():
     lib = _lib.load()
     torch.cuda.set_device(0)
     ctx = Context(0)
-    size, batch, gmax = 640, 64, 1024                        # 64 * 1024 * 200 B of tables
+    size, batch, gmax = 64, 256, 4096                        # 256 * 4096 keys of 8 B = 8 MiB
+    assert batch * gmax * 8 > _lib.STATIC_SCRATCH_BYTES
     geom = geometry_for(ssd_config(size), 0)
     A = geom.num_anchors
     boxes = torch.zeros((batch, gmax, 4), dtype=torch.float32, device="cuda")
+    boxes[:, :, 2:] = 0.5
     labels = torch.ones((batch, gmax), dtype=torch.float32, device="cuda")
     counts = torch.ones((batch,), dtype=torch.int32, device="cuda")
-    conf = torch.empty((1,), dtype=torch.float32, device="cuda")   # never written: the call is refused
+    # outputs of full size: a call that was wrongly accepted would still write inside them
+    conf = torch.full((batch, A), -7.0, dtype=torch.float32, device="cuda")
+    locs = torch.full((batch, A, 4), -7.0, dtype=torch.float32, device="cuda")
     rc = lib.ssdbox_match_encode_static(ctx.handle, geom.handle, None, A, _p(boxes), _p(labels), _p(counts),
-                                        batch, gmax, float(size), 0.5, _p(conf), _p(conf), None, None)
+                                        batch, gmax, float(size), 0.5, _p(conf), _p(locs), None, None)
     assert rc == _lib.ERR_INVALID
     assert b"fixed array" in lib.ssdbox_last_error()
+    ctx.synchronize()
+    assert bool((conf == -7.0).all())                        # nothing was launched

@@ -27,6 +27,12 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak
 
+# HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default); two batch streams
+# that share one run one after the other.  Eight queues leave each of the four batch streams one of
+# its own next to the streams PyTorch creates (measured: 9.2e5 images/s against 8.9e5).  Must be set
+# before the HIP runtime starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 
 def parse_args():
     ap = argparse.ArgumentParser()

@@ -496,7 +496,7 @@ def main():
     n_loss = max(args.steps // 4, 10)
 
     # the optional collective, outside the timed loop: every rank receives all detections
-    allgather_ms = None
+    allgather_ms = allgather_ok = None
     if world > 1:
         slot = wl.slots[0]
         gb = args.batch * world
@@ -510,6 +510,22 @@ def main():
                 fdist.all_gather_detections(slot["dets"], slot["keep"], slot["count"], gb)
             torch.cuda.synchronize()
             allgather_ms = (time.perf_counter() - t0) / 10 * 1e3
+            # what rank 0 received against what it computes itself from every rank's inputs
+            g_dets, g_keep, g_count = fdist.all_gather_detections(slot["dets"], slot["keep"], slot["count"], gb)
+            if rank == 0:
+                allgather_ok = True
+                mine = wl.d_ypred
+                for r in range(world):
+                    wl.d_ypred = torch.from_numpy(make_inputs(args, r)[4]).to(mine.device)
+                    wl.detect(slot)
+                    torch.cuda.synchronize()
+                    sl = slice(r * args.batch, (r + 1) * args.batch)
+                    allgather_ok = allgather_ok and bool(torch.equal(g_count[sl], slot["count"])) and \
+                        bool(torch.equal(g_keep[sl], slot["keep"])) and \
+                        bool(torch.equal(g_dets[sl].view(torch.int32), slot["dets"].view(torch.int32)))
+                wl.d_ypred = mine
+                wl.detect(slot)
+                torch.cuda.synchronize()
         except Exception as e:
             print("rank %d: all-gather of detections failed: %r" % (rank, e), file=sys.stderr)
 
@@ -598,6 +614,7 @@ def main():
         out["single_image_decode_nms_latency_ms"] = lat1 * 1e3
         if allgather_ms is not None:
             out["allgather_detections_ms"] = allgather_ms
+            out["allgather_equals_local_recompute"] = allgather_ok
         step_s = elapsed / args.steps
         pcie["images_per_s_with_transfers_serial"] = args.batch / (step_s + (pcie["h2d_ms"] + pcie["d2h_ms"]) * 1e-3)
         out["pcie"] = pcie

@@ -5,10 +5,42 @@ utils/box_utils.py:47-98, called per image at utils/datasets.py:152); decode_nms
 replaces the per-image post-processing block of reference inference.py:33-83.  Results
 equal that loop image by image.
 """
+import functools
+
 import numpy as np
 
 from . import _lib
 from .runtime import AnchorGrid, _ptr, default_context, from_device, require_gpu, to_device
+
+
+def _on_context_stream(fn):
+    """With context=None a call runs on the current stream.  A context given by the caller may be
+    bound to another stream: the kernels run there, so everything else the call does must too.
+    The context's stream first waits for the current one (inputs), the whole body -- allocations,
+    copies, launches, copies back to the host -- runs with the context's stream current, and the
+    current stream then waits for it, with the returned CUDA tensors marked as used there."""
+    @functools.wraps(fn)
+    def wrapper(*args, context=None, **kwargs):
+        if context is None:
+            return fn(*args, context=None, **kwargs)
+        torch = require_gpu()
+        current = torch.cuda.current_stream(context.device)
+        stream = context.stream
+        handle = stream.cuda_stream if hasattr(stream, "cuda_stream") else int(stream)
+        if handle == current.cuda_stream:
+            return fn(*args, context=context, **kwargs)
+        if not isinstance(stream, torch.cuda.Stream):
+            raise ValueError("a context bound to a raw stream handle can only be used while that stream is "
+                             "the current one; bind it to a torch.cuda.Stream instead")
+        stream.wait_stream(current)
+        with torch.cuda.stream(stream):
+            res = fn(*args, context=context, **kwargs)
+        current.wait_stream(stream)
+        for r in (res if isinstance(res, tuple) else (res,)):
+            if isinstance(r, torch.Tensor) and r.is_cuda:
+                r.record_stream(current)
+        return res
+    return wrapper
 
 
 def _anchor_source(anchors, device):
@@ -24,6 +56,7 @@ def _anchor_source(anchors, device):
     return None, t, int(t.shape[0]), t
 
 
+@_on_context_stream
 def match_encode_batch(anchors, gt_boxes, gt_count, gt_labels=None, max_size=512.0,
                        iou_threshold=0.5, y_true=False, return_match=False, context=None):
     """Training targets for a batch.
@@ -77,6 +110,7 @@ def match_encode_batch(anchors, gt_boxes, gt_count, gt_labels=None, max_size=512
     return res
 
 
+@_on_context_stream
 def decode_nms_batch(anchors, y_pred, score_threshold, nms_threshold=0.45, limit=1000,
                      img_wh=None, context=None, from_logits=False):
     """Detections for a batch of head outputs.
@@ -117,6 +151,7 @@ def decode_nms_batch(anchors, y_pred, score_threshold, nms_threshold=0.45, limit
     return from_device(dets, family), from_device(keep, family), from_device(count, family)
 
 
+@_on_context_stream
 def prepare_gt_batch(raw_xywh, gt_count, img_wh, target_hw, shrink=None, context=None):
     """Annotation boxes of a batch to the normalised corners match_encode_batch takes.
 
@@ -152,6 +187,7 @@ def prepare_gt_batch(raw_xywh, gt_count, img_wh, target_hw, shrink=None, context
     return from_device(out, family)
 
 
+@_on_context_stream
 def widerface_rows_batch(dets, count, context=None):
     """Detections of decode_nms_batch (pixels of the original image) to the integer rows of
     WiderFace result files, reference evaluation.py:69-76.  dets (B,limit,6), count (B,) ->
@@ -173,6 +209,7 @@ def widerface_rows_batch(dets, count, context=None):
     return from_device(xywh, family), from_device(scores, family)
 
 
+@_on_context_stream
 def ssd_loss_batch(y_true, y_pred, neg_pos_ratio=3, n_neg_min=0, alpha=1.0, return_keep=False,
                    return_grad=False, context=None):
     """SSD loss with hard-negative mining, reference utils/losses.py:97-181 (SSDLoss.call).

@@ -164,16 +164,12 @@ extern "C" int ssdbox_ctx_set_stream(ssdbox_ctx *ctx, void *stream, int own_stre
     SSD_REQUIRE(ctx != nullptr, "ssdbox_ctx_set_stream: ctx is NULL");
     DeviceGuard guard(ctx->device);
     SSD_CHECK_HIP(hipStreamSynchronize(ctx->stream));     // scratch is tied to stream order
-    if (ctx->owns_stream) {
-        SSD_CHECK_HIP(hipStreamDestroy(ctx->stream));
-        ctx->owns_stream = false;
-    }
-    if (own_stream != 0) {
-        SSD_CHECK_HIP(create_own_stream(&ctx->stream));
-        ctx->owns_stream = true;
-    } else {
-        ctx->stream = (hipStream_t)stream;
-    }
+    // the new stream exists before the old one goes: a failure leaves the context as it was
+    hipStream_t next = (hipStream_t)stream;
+    if (own_stream != 0) SSD_CHECK_HIP(create_own_stream(&next));
+    if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
+    ctx->stream = next;
+    ctx->owns_stream = (own_stream != 0);
     return SSDBOX_OK;
 }
 
@@ -202,15 +198,26 @@ extern "C" int ssdbox_ctx_collect_timing(ssdbox_ctx *ctx, float *ms, int32_t *la
         launches[s] = 0;
     }
     SSD_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    // Every record leaves the list and every event returns to the pool whatever happens; the
+    // first error is reported once the bookkeeping is consistent.
+    hipError_t first = hipSuccess;
     for (auto &r : ctx->records) {
         float t = 0.0f;
-        SSD_CHECK_HIP(hipEventElapsedTime(&t, r.start, r.stop));
-        ms[r.stage] += t;
-        launches[r.stage] += 1;
+        const hipError_t e = hipEventElapsedTime(&t, r.start, r.stop);
+        if (e == hipSuccess) {
+            ms[r.stage] += t;
+            launches[r.stage] += 1;
+        } else if (first == hipSuccess) {
+            first = e;
+        }
         ctx->event_pool.push_back(r.start);
         ctx->event_pool.push_back(r.stop);
     }
     ctx->records.clear();
+    if (first != hipSuccess) {
+        set_error("ssdbox_ctx_collect_timing: hipEventElapsedTime failed: %s", hipGetErrorString(first));
+        return SSDBOX_ERR_HIP;
+    }
     return SSDBOX_OK;
 }
 

@@ -62,6 +62,8 @@ struct ssdbox_geom {
 // ---------------------------------------------------------------------------------------
 // Context: stream, scratch, optional per-stage event timing.
 // ---------------------------------------------------------------------------------------
+constexpr size_t kMaxTimingRecords = 1u << 16;   // launches recorded between two collects
+
 struct TimingRecord {
     int stage;
     hipEvent_t start, stop;
@@ -164,7 +166,7 @@ void launch_stage(ssdbox_ctx *ctx, int stage, void (*kernel)(KArgs...), dim3 gri
                   Args &&...args)
 {
     hipEvent_t ev[2];
-    if (ctx->timing && acquire_events(ctx, ev)) {
+    if (ctx->timing && ctx->records.size() < kMaxTimingRecords && acquire_events(ctx, ev)) {
         hipExtLaunchKernelGGL<KArgs...>(kernel, grid, block, 0u, ctx->stream, ev[0], ev[1], 0u,
                                         static_cast<KArgs>(args)...);
         ctx->records.push_back({stage, ev[0], ev[1]});

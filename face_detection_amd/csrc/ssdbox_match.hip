@@ -632,7 +632,7 @@ int launch_match(ssdbox_ctx *ctx, const MatchArgs &args, int batch, int n_tiles,
     const dim3 grid(n_tiles, batch);
     const bool details = args.match_idx != nullptr || args.match_iou != nullptr;
     hipEvent_t ev[2] = {nullptr, nullptr};
-    const bool timed = ctx->timing && acquire_events(ctx, ev);
+    const bool timed = ctx->timing && ctx->records.size() < kMaxTimingRecords && acquire_events(ctx, ev);
     void (*kernel)(const MatchArgs);
     if (!GEOM)
         kernel = details ? match_array_kernel<YTRUE, true> : match_array_kernel<YTRUE, false>;

@@ -171,6 +171,7 @@ class AnchorGrid:
         self.ndim = 2
         self._dev = None
         self._host = None
+        self._lock = threading.Lock()
 
     def __len__(self):
         return self.shape[0]
@@ -178,12 +179,18 @@ class AnchorGrid:
     def tensor(self):
         """The materialised anchors as a CUDA torch tensor."""
         if self._dev is None:
-            torch = _torch()
-            out = torch.empty(self.shape, dtype=torch.float32, device="cuda:%d" % self.device)
-            with torch.cuda.device(self.device):
-                ctx = default_context(self.device)
-                _lib.check(ctx.lib.ssdbox_generate_anchors(ctx.handle, self.geometry.handle, _ptr(out)))
-            self._dev = out
+            # The object is shared between threads and streams (the reference hands one anchor
+            # array to six tf.data workers): one of them materialises it, and it is published
+            # only when the kernel has finished, so that any stream may read it.
+            with self._lock:
+                if self._dev is None:
+                    torch = _torch()
+                    out = torch.empty(self.shape, dtype=torch.float32, device="cuda:%d" % self.device)
+                    with torch.cuda.device(self.device):
+                        ctx = default_context(self.device)
+                        _lib.check(ctx.lib.ssdbox_generate_anchors(ctx.handle, self.geometry.handle, _ptr(out)))
+                        ctx.synchronize()
+                    self._dev = out
         return self._dev
 
     def numpy(self):

@@ -31,8 +31,7 @@ def build(force=False):
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(_SO):
-            build()
+        build()                      # also rebuilds a library older than its source
         L = ctypes.CDLL(_SO)
         L.orc_logf.restype = ctypes.c_float
         L.orc_logf.argtypes = [ctypes.c_float]

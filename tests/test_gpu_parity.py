@@ -482,3 +482,82 @@ def test_six_threads_each_with_a_context(fda):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_context_on_another_stream_is_ordered(fda):
+    """A caller-supplied context bound to a stream that is not the current one: inputs produced on
+    the current stream are seen, results are complete when the current stream (or the host) reads
+    them."""
+    import torch
+    from face_detection_amd.runtime import Context
+    cfg = ssd_config(256)
+    anchors_np = O.generate_anchors(cfg)
+    grid = fda.anchor_utils.generate_anchors(cfg)
+    rng = np.random.default_rng(31)
+    boxes, labels, counts = S.make_ground_truth(rng, 6, 256, gmax=32)
+    y = S.make_head_outputs(rng, cfg, boxes, counts, n_ties=8)
+    side = torch.cuda.Stream()
+    ctx = Context(0, side)
+    assert side.cuda_stream != torch.cuda.current_stream().cuda_stream
+    for _ in range(3):
+        # inputs written on the current stream right before the call
+        d_boxes = torch.from_numpy(boxes).cuda() * 1.0
+        d_labels = torch.from_numpy(labels).cuda() * 1.0
+        d_y = torch.from_numpy(y).cuda() * 1.0
+        conf, locs = fda.match_encode_batch(grid, d_boxes, counts, d_labels, 256.0, context=ctx)
+        dets, keep, count = fda.decode_nms_batch(grid, d_y, 0.05, context=ctx)
+        total = conf.sum() + locs.sum() + dets.sum()            # consumed on the current stream
+        n_conf, n_locs = fda.match_encode_batch(grid, boxes, counts, labels, 256.0, context=ctx)   # numpy out
+        assert torch.isfinite(total)
+        for b in range(6):
+            g = counts[b]
+            c_conf, c_locs = C.compute_target(anchors_np, boxes[b, :g], labels[b, :g], 256.0)
+            np.testing.assert_array_equal(conf[b].cpu().numpy(), c_conf)
+            np.testing.assert_array_equal(n_conf[b], c_conf)
+            assert_bits_equal(locs[b].cpu().numpy(), c_locs)
+            assert_bits_equal(n_locs[b], c_locs)
+            c_dets, c_idx = C.postprocess(y[b], anchors_np, 0.05)
+            n = int(count[b])
+            np.testing.assert_array_equal(keep[b, :n].cpu().numpy(), c_idx)
+            assert_bits_equal(dets[b, :n].cpu().numpy(), c_dets)
+    with pytest.raises(ValueError):
+        fda.decode_nms_batch(grid, y, 0.05, context=Context(0, side.cuda_stream))   # raw handle, not current
+
+
+def test_context_set_stream(fda):
+    """ssdbox_ctx_set_stream: from a caller's stream to a stream of the context's own and back."""
+    import ctypes
+    import torch
+    from face_detection_amd import _lib
+    from face_detection_amd.runtime import Context
+    lib = _lib.load()
+    cfg = ssd_config(128)
+    anchors_np = O.generate_anchors(cfg)
+    grid = fda.anchor_utils.generate_anchors(cfg)
+    rng = np.random.default_rng(32)
+    boxes, labels, counts = S.make_ground_truth(rng, 2, 128, gmax=8)
+    ctx = Context(0)
+    want = [C.compute_target(anchors_np, boxes[b, :counts[b]], labels[b, :counts[b]], 128.0) for b in range(2)]
+    d = [torch.from_numpy(x).cuda() for x in (boxes, labels, counts)]
+    A = len(anchors_np)
+
+    def run():
+        conf = torch.empty((2, A), dtype=torch.float32, device="cuda")
+        locs = torch.empty((2, A, 4), dtype=torch.float32, device="cuda")
+        _lib.check(lib.ssdbox_match_encode(ctx.handle, grid.geometry.handle, None, A, *(ctypes.c_void_p(t.data_ptr()) for t in d),
+                                           2, 8, 128.0, 0.5, ctypes.c_void_p(conf.data_ptr()),
+                                           ctypes.c_void_p(locs.data_ptr()), None, None))
+        ctx.synchronize()
+        for b in range(2):
+            np.testing.assert_array_equal(conf[b].cpu().numpy(), want[b][0])
+            assert_bits_equal(locs[b].cpu().numpy(), want[b][1])
+
+    torch.cuda.synchronize()
+    run()
+    _lib.check(lib.ssdbox_ctx_set_stream(ctx.handle, None, 1))                       # a stream of its own
+    run()
+    _lib.check(lib.ssdbox_ctx_set_stream(ctx.handle, None, 1))                       # own -> own
+    run()
+    s = torch.cuda.Stream()
+    _lib.check(lib.ssdbox_ctx_set_stream(ctx.handle, ctypes.c_void_p(s.cuda_stream), 0))   # own -> caller's
+    run()

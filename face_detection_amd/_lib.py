@@ -4,7 +4,9 @@ There is no CPU fallback: if the library has not been built, or no MI355X is vis
 every entry point of this package raises.
 """
 import ctypes
+import importlib.util
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SSDBOX_LIB selects another build of the same library (kernel experiments); never a fallback.
@@ -44,6 +46,16 @@ SIGNATURES = {
     "ssdbox_ctx_synchronize": (_i, [_vp]),
     "ssdbox_ctx_set_timing": (_i, [_vp, _i]),
     "ssdbox_ctx_collect_timing": (_i, [_vp, _pf, _pi32]),
+    "ssdbox_device_count": (_i, []),
+    "ssdbox_buf_alloc": (_i, [_vp, ctypes.c_size_t, ctypes.POINTER(_vp)]),
+    "ssdbox_buf_free": (_i, [_vp, _vp]),
+    "ssdbox_copy_h2d": (_i, [_vp, _vp, _vp, ctypes.c_size_t]),
+    "ssdbox_copy_d2h": (_i, [_vp, _vp, _vp, ctypes.c_size_t]),
+    "ssdbox_copy_d2d": (_i, [_vp, _vp, _vp, ctypes.c_size_t]),
+    "ssdbox_dlpack_import": (_i, [_vp, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_i64), _pi32, _pi32, _pi32]),
+    "ssdbox_dlpack_export": (_i, [_vp, _vp, ctypes.c_int32, ctypes.POINTER(_i64), ctypes.c_int32, ctypes.c_int32,
+                                  ctypes.POINTER(_vp)]),
+    "ssdbox_dlpack_delete": (_i, [_vp]),
     "ssdbox_geom_create": (_i, [_i, _i, _i, _i, _pi32, _pd, _pi32, _pd, _i, _d, ctypes.POINTER(_vp)]),
     "ssdbox_geom_destroy": (_i, [_vp]),
     "ssdbox_geom_num_anchors": (_i64, [_vp]),
@@ -74,6 +86,30 @@ class SsdboxError(RuntimeError):
     """A libssdbox call failed (HIP error, allocation failure)."""
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch wheels bundle their own libamdhip64.so; a process that
+    initialises two copies of the runtime sees the GPU through the first one only (the other one
+    reports no device).  If torch is imported already its copy is in the process and libssdbox
+    binds to it.  If torch is installed but not imported yet, its copy is loaded first, so that a
+    later `import torch` finds the runtime it ships with already in place; without torch the
+    system's /opt/rocm runtime is used."""
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+        locations = list(spec.submodule_search_locations) if spec is not None else []
+    except (ImportError, ValueError, AttributeError):
+        return
+    for loc in locations:
+        cand = os.path.join(loc, "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            try:
+                ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+            except OSError:
+                pass
+            return
+
+
 def load():
     global _lib
     if _lib is not None:
@@ -83,6 +119,7 @@ def load():
             "libssdbox.so is not built (%s missing): run `make -C face_detection_amd/csrc` or "
             "`python -c 'import __graft_entry__ as g; g.build()'`; this package has no CPU "
             "fallback" % LIB_PATH)
+    _preload_hip_runtime()
     lib = ctypes.CDLL(LIB_PATH)
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(lib, name)

@@ -124,6 +124,11 @@ extern "C" int ssdbox_ctx_create(int device, void *stream, int own_stream, ssdbo
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     ctx->static_scratch = static_cast<unsigned char *>(scratch_ptr);
     ctx->static_scratch_bytes = kStaticScratchBytes;
+    ctx->buf_cached = 0;
+    ctx->stage[0] = ctx->stage[1] = nullptr;
+    ctx->stage_ev[0] = ctx->stage_ev[1] = nullptr;
+    ctx->stage_busy[0] = ctx->stage_busy[1] = false;
+    ctx->stage_next = 0;
     ctx->owns_stream = (own_stream != 0);
     ctx->timing = false;
     if (ctx->owns_stream) {
@@ -154,6 +159,7 @@ extern "C" int ssdbox_ctx_destroy(ssdbox_ctx *ctx)
                     ctx->sidx, ctx->keff, ctx->mask, ctx->selftest_out};
     for (void *b : bufs)
         if (b != nullptr) (void)hipFree(b);
+    free_buffer_state(ctx);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return SSDBOX_OK;
@@ -234,6 +240,7 @@ extern "C" int ssdbox_geom_create(int device, int img_width, int img_height, int
                 "ssdbox_geom_create: n_layers %d outside [1, %d]", n_layers, SSDBOX_MAX_LAYERS);
     SSD_REQUIRE(img_width > 0 && img_height > 0, "ssdbox_geom_create: image %dx%d", img_width,
                 img_height);
+    try {                       // the tables grow in std::vector: nothing may throw across the ABI
 
     GeomDev g;
     memset(&g, 0, sizeof(g));
@@ -339,7 +346,7 @@ extern "C" int ssdbox_geom_create(int device, int img_width, int img_height, int
     g.num_anchors = (int)total;
     g.n_tiles = tiles;
 
-    ssdbox_geom *geom = new ssdbox_geom();
+    ssdbox_geom *geom = new ssdbox_geom();     // (a failure is caught below)
     geom->device = device;
     geom->host = g;
     geom->d_geom = nullptr;
@@ -378,6 +385,11 @@ extern "C" int ssdbox_geom_create(int device, int img_width, int img_height, int
     }
     *out = geom;
     return SSDBOX_OK;
+
+    } catch (...) {
+        set_error("ssdbox_geom_create: out of host memory");
+        return SSDBOX_ERR_NOMEM;
+    }
 }
 
 extern "C" int ssdbox_geom_destroy(ssdbox_geom *geom)

@@ -69,6 +69,11 @@ struct TimingRecord {
     hipEvent_t start, stop;
 };
 
+struct DeviceBuf {
+    void *ptr;
+    size_t bytes;
+};
+
 struct ssdbox_ctx {
     int device;
     int num_cus;                   // compute units of the device (sizes the persistent grids)
@@ -105,6 +110,15 @@ struct ssdbox_ctx {
     size_t det_cap;                // images
     int *selftest_out;
 
+    // buffer surface (ssdbox_buf.hip): buffers handed out, freed buffers kept for reuse, and the
+    // pinned staging ring of the host <-> device copies
+    std::vector<DeviceBuf> buf_live, buf_free;
+    size_t buf_cached;
+    void *stage[2];
+    hipEvent_t stage_ev[2];
+    bool stage_busy[2];
+    int stage_next;
+
     // This device's copy of the library's fixed scratch array (ssdbox_ctx.hip), resolved when
     // the context is created: what the entry point that allocates nothing works in.
     unsigned char *static_scratch;
@@ -112,6 +126,7 @@ struct ssdbox_ctx {
 };
 
 void set_error(const char *fmt, ...);
+void free_buffer_state(ssdbox_ctx *ctx);   // ssdbox_buf.hip
 
 #define SSD_CHECK_HIP(expr)                                                              \
     do {                                                                                 \
@@ -169,7 +184,10 @@ void launch_stage(ssdbox_ctx *ctx, int stage, void (*kernel)(KArgs...), dim3 gri
     if (ctx->timing && ctx->records.size() < kMaxTimingRecords && acquire_events(ctx, ev)) {
         hipExtLaunchKernelGGL<KArgs...>(kernel, grid, block, 0u, ctx->stream, ev[0], ev[1], 0u,
                                         static_cast<KArgs>(args)...);
-        ctx->records.push_back({stage, ev[0], ev[1]});
+        try {
+            ctx->records.push_back({stage, ev[0], ev[1]});
+        } catch (...) {               // the launch stays, its timing is dropped
+        }
     } else {
         hipLaunchKernelGGL(kernel, grid, block, 0, ctx->stream, static_cast<KArgs>(args)...);
     }

@@ -641,7 +641,12 @@ int launch_match(ssdbox_ctx *ctx, const MatchArgs &args, int batch, int n_tiles,
     else
         kernel = details ? match_geom_kernel<YTRUE, true, false> : match_geom_kernel<YTRUE, false, false>;
     hipExtLaunchKernelGGL(kernel, grid, dim3(kBlock), (unsigned)lds_bytes, ctx->stream, ev[0], ev[1], 0u, args);
-    if (timed) ctx->records.push_back({SSDBOX_STAGE_MATCH, ev[0], ev[1]});
+    if (timed) {
+        try {
+            ctx->records.push_back({SSDBOX_STAGE_MATCH, ev[0], ev[1]});
+        } catch (...) {               // the launch stays, its timing is dropped
+        }
+    }
     SSD_CHECK_HIP(hipGetLastError());
     launch_stage(ctx, SSDBOX_STAGE_FORCE, force_kernel<GEOM, YTRUE>, dim3(batch), dim3(kBlock), args);
     SSD_CHECK_HIP(hipGetLastError());

@@ -8,44 +8,52 @@ import numpy as np
 
 from .. import _lib
 from ..batched import _anchor_source, match_encode_batch
-from ..runtime import AnchorGrid, _ptr, default_context, from_device, require_gpu, to_device
+from ..runtime import AnchorGrid, Session, _is_torch_tensor, _ptr, _torch
 
 
 def _rows4(t, what):
-    if t.dim() < 1 or t.shape[-1] != 4:
+    if len(t.shape) < 1 or t.shape[-1] != 4:
         raise ValueError("%s must have a last dimension of 4, got %s" % (what, tuple(t.shape)))
 
 
 def compute_area(top_left, bot_right, max_size=512.0):
     """Area of boxes given (..., 2) corners, sides clipped to [0, max_size]
     (reference utils/box_utils.py:4-18)."""
-    torch = require_gpu()
-    ctx = default_context()
-    tl, family = to_device(top_left, np.float32)
-    br, _ = to_device(bot_right, np.float32)
-    tl, br = torch.broadcast_tensors(tl, br)
-    tl, br = tl.contiguous(), br.contiguous()
+    sess = Session(top_left, bot_right)
+    ctx = sess.ctx
+    if _is_torch_tensor(top_left) or _is_torch_tensor(bot_right):
+        torch = _torch()
+        tl, family = sess.put(top_left, np.float32)
+        br, _ = sess.put(bot_right, np.float32)
+        tl, br = torch.broadcast_tensors(tl, br)
+        tl, br = tl.contiguous(), br.contiguous()
+    else:
+        tl, family = sess.put(top_left, np.float32)
+        br, fam_b = sess.put(bot_right, np.float32)
+        if tuple(tl.shape) != tuple(br.shape):     # broadcast on the host, then upload
+            h_tl, h_br = np.broadcast_arrays(sess.host(tl), sess.host(br))
+            tl, br = sess.put(np.ascontiguousarray(h_tl), np.float32)[0], sess.put(np.ascontiguousarray(h_br), np.float32)[0]
     if tl.shape[-1] != 2:
         raise ValueError("corners must have a last dimension of 2")
-    out = torch.empty(tl.shape[:-1], dtype=torch.float32, device=tl.device)
+    out = sess.empty(tuple(tl.shape[:-1]))
     _lib.check(ctx.lib.ssdbox_compute_area(ctx.handle, _ptr(tl), _ptr(br), out.numel(),
                                            float(max_size), _ptr(out)))
-    return from_device(out, family, top_left)
+    return sess.get(out, family, top_left)
 
 
 def compute_iou(boxes_a, boxes_b, max_size=512.0):
     """(Na,4),(Nb,4) corner boxes -> (Na,Nb) IoU, no epsilon
     (reference utils/box_utils.py:21-44)."""
-    torch = require_gpu()
-    ctx = default_context()
-    a, family = to_device(boxes_a, np.float32)
-    b, _ = to_device(boxes_b, np.float32)
+    sess = Session(boxes_a, boxes_b)
+    ctx = sess.ctx
+    a, family = sess.put(boxes_a, np.float32)
+    b, _ = sess.put(boxes_b, np.float32)
     if a.dim() != 2 or b.dim() != 2 or a.shape[1] != 4 or b.shape[1] != 4:
         raise ValueError("compute_iou takes (Na,4) and (Nb,4) boxes")
-    out = torch.empty((a.shape[0], b.shape[0]), dtype=torch.float32, device=a.device)
+    out = sess.empty((a.shape[0], b.shape[0]))
     _lib.check(ctx.lib.ssdbox_compute_iou(ctx.handle, _ptr(a), a.shape[0], _ptr(b), b.shape[0],
                                           float(max_size), _ptr(out)))
-    return from_device(out, family, boxes_a)
+    return sess.get(out, family, boxes_a)
 
 
 def compute_target(default_boxes, gt_boxes, gt_labels, max_size=512.0, iou_threshold=0.5):
@@ -53,45 +61,49 @@ def compute_target(default_boxes, gt_boxes, gt_labels, max_size=512.0, iou_thres
     (reference utils/box_utils.py:47-98): returns (gt_confs (A,), gt_locs (A,4)).
     default_boxes may be the object generate_anchors returned (anchors are then built on
     the fly) or any (A,4) [cx,cy,w,h] array."""
-    require_gpu()
     gt = np.asarray(gt_boxes) if not hasattr(gt_boxes, "shape") else gt_boxes
     if len(gt.shape) != 2 or gt.shape[1] != 4:
         raise ValueError("gt_boxes must have shape (G, 4), got %s" % (tuple(gt.shape),))
     G = int(gt.shape[0])
     if G == 0:
         raise ValueError("compute_target needs at least one ground-truth box")
-    boxes, family = to_device(gt_boxes, np.float32)
-    labels, _ = to_device(gt_labels, np.float32)
+    sess = Session(default_boxes, gt_boxes, gt_labels)
+    boxes, family = sess.put(gt_boxes, np.float32)
+    labels, _ = sess.put(gt_labels, np.float32)
     if tuple(labels.shape) != (G,):
         raise ValueError("gt_labels must have shape (%d,)" % G)
+    # (device arrays in, device arrays out: the batched call returns what it is given)
     conf, locs = match_encode_batch(default_boxes, boxes[None], np.array([G], np.int32),
-                                    labels[None], max_size, iou_threshold)
+                                    labels[None], max_size, iou_threshold, _device_results=True)
     conf, locs = conf[0], locs[0]
     label_dtype = getattr(gt_labels, "dtype", None)
-    conf = from_device(conf, family, gt_boxes)
-    locs = from_device(locs, family, gt_boxes)
-    if family == "numpy" and label_dtype is not None and np.dtype(label_dtype) != np.float32:
-        conf = conf.astype(label_dtype)
+    conf = sess.get(conf, family, gt_boxes)
+    locs = sess.get(locs, family, gt_boxes)
+    if family == "numpy" and label_dtype is not None:
+        try:
+            if np.dtype(label_dtype) != np.float32:
+                conf = conf.astype(label_dtype)
+        except TypeError:
+            pass
     return conf, locs
 
 
 def _codec(fn_name, default_boxes, values, variance):
-    torch = require_gpu()
     if variance is None:
         variance = [0.1, 0.2]
-    ctx = default_context()
-    device = torch.cuda.current_device()
-    v, family = to_device(values, np.float32)
+    sess = Session(default_boxes, values)
+    ctx = sess.ctx
+    v, family = sess.put(values, np.float32)
     _rows4(v, "boxes")
-    geom, anc, A, _keep = _anchor_source(default_boxes, device)
+    geom, anc, A, _keep = _anchor_source(sess, default_boxes)
     if v.dim() < 2 or v.shape[-2] != A:
         raise ValueError("expected (..., %d, 4) values for %d default boxes, got %s"
                          % (A, A, tuple(v.shape)))
-    out = torch.empty_like(v)
+    out = sess.empty(tuple(v.shape))
     fn = getattr(ctx.lib, fn_name)
     _lib.check(fn(ctx.handle, geom, _ptr(anc), A, _ptr(v), v.numel() // 4, float(variance[0]),
                   float(variance[1]), _ptr(out)))
-    return from_device(out, family, values)
+    return sess.get(out, family, values)
 
 
 def encode(default_boxes, boxes, variance=None):
@@ -107,18 +119,13 @@ def decode(default_boxes, locs, variance=None):
 
 
 def _transform(fn_name, boxes):
-    torch = require_gpu()
-    ctx = default_context()
-    if isinstance(boxes, AnchorGrid):
-        boxes = boxes.tensor()
-        family = "numpy"
-        b = boxes
-    else:
-        b, family = to_device(boxes, np.float32)
+    sess = Session(boxes)
+    ctx = sess.ctx
+    b, family = sess.put(boxes, np.float32)
     _rows4(b, "boxes")
-    out = torch.empty_like(b)
+    out = sess.empty(tuple(b.shape))
     _lib.check(getattr(ctx.lib, fn_name)(ctx.handle, _ptr(b), b.numel() // 4, _ptr(out)))
-    return from_device(out, family, boxes)
+    return sess.get(out, family, boxes)
 
 
 def transform_corner_to_center(boxes):
@@ -135,21 +142,21 @@ def compute_nms(boxes, scores, nms_threshold, limit=200):
     """Greedy NMS over the `limit` best-scoring boxes; returns the int32 indices of the kept
     boxes in descending-score order (reference utils/box_utils.py:184-222).  Empty input
     gives an empty int32 result."""
-    torch = require_gpu()
-    ctx = default_context()
-    b, family = to_device(boxes, np.float32)
-    s, _ = to_device(scores, np.float32)
+    sess = Session(boxes, scores)
+    ctx = sess.ctx
+    b, family = sess.put(boxes, np.float32)
+    s, _ = sess.put(scores, np.float32)
     n = int(b.shape[0])
     if n == 0:
-        return from_device(torch.empty((0,), dtype=torch.int32, device=b.device), family, boxes)
+        return sess.get(sess.empty((0,), np.int32), family, boxes)
     if b.dim() != 2 or b.shape[1] != 4 or tuple(s.shape) != (n,):
         raise ValueError("compute_nms takes (N,4) boxes and (N,) scores")
     if not float(nms_threshold) < 1.0:
         raise ValueError("nms_threshold must be < 1 (the reference loop never ends otherwise)")
     k = min(int(limit), n)
-    keep = torch.empty((k,), dtype=torch.int32, device=b.device)
-    count = torch.empty((1,), dtype=torch.int32, device=b.device)
+    keep = sess.empty((k,), np.int32)
+    count = sess.empty((1,), np.int32)
     _lib.check(ctx.lib.ssdbox_compute_nms(ctx.handle, _ptr(b), _ptr(s), n, float(nms_threshold),
                                           int(limit), _ptr(keep), _ptr(count)))
-    keep = keep[: int(count.item())]
-    return from_device(keep, family, boxes)
+    keep = keep[: int(sess.host(count)[0])]
+    return sess.get(keep, family, boxes)

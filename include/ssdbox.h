@@ -18,6 +18,7 @@
 #ifndef SSDBOX_H
 #define SSDBOX_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -70,6 +71,44 @@ int ssdbox_ctx_synchronize(ssdbox_ctx *ctx);            /* blocks the host */
  * launches[SSDBOX_NUM_STAGES] and clears the records. */
 int ssdbox_ctx_set_timing(ssdbox_ctx *ctx, int enabled);
 int ssdbox_ctx_collect_timing(ssdbox_ctx *ctx, float *ms, int32_t *launches);
+
+/* ---- buffers: what a host binding needs to exchange arrays without any other GPU library ---- */
+/* The reference's callers pass numpy arrays (utils/datasets.py:130-152) and tf.Tensors
+ * (inference.py:38-60) and get tf.Tensors back; there is no counterpart of these calls in the
+ * reference because TensorFlow owns its memory there.  With them the Python layer needs PyTorch
+ * only when the caller passes torch tensors.
+ * ssdbox_device_count: GPUs visible to the process (0 when there is none or HIP fails).
+ * ssdbox_buf_alloc / _free: device memory on the context's GPU; a freed buffer may be handed out
+ *   again by a later ssdbox_buf_alloc of the same context (safe in stream order), everything is
+ *   released with the context.
+ * ssdbox_copy_h2d: host memory (pageable is fine) -> device through the context's pinned staging
+ *   ring, enqueued on the context's stream; returns once h_src may be reused.
+ * ssdbox_copy_d2h: device -> host the same way; returns when h_dst holds the data (and with it
+ *   everything enqueued on the stream before has finished).
+ * ssdbox_copy_d2d: device -> device on the context's stream. */
+int ssdbox_device_count(void);
+int ssdbox_buf_alloc(ssdbox_ctx *ctx, size_t bytes, void **d_out);
+int ssdbox_buf_free(ssdbox_ctx *ctx, void *d_ptr);
+int ssdbox_copy_h2d(ssdbox_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+int ssdbox_copy_d2h(ssdbox_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+int ssdbox_copy_d2d(ssdbox_ctx *ctx, void *d_dst, const void *d_src, size_t bytes);
+/* DLPack exchange (what tf.experimental.dlpack.to_dlpack / from_dlpack, torch and numpy's
+ * __dlpack__ produce and consume).  dl_managed_tensor is a DLManagedTensor* as dlpack.h defines it.
+ * ssdbox_dlpack_import: a dense row-major tensor to a device pointer of the context's GPU.  A
+ *   tensor in GPU memory (kDLROCM, same device) is used in place (*owned = 0: the caller keeps the
+ *   producer alive until the work enqueued with it has finished); a tensor in host memory (kDLCPU,
+ *   pinned host) is staged into a new buffer (*owned = 1: release it with ssdbox_buf_free).  The
+ *   library never calls the tensor's deleter: inputs stay the caller's.
+ * ssdbox_dlpack_export: wraps a buffer from ssdbox_buf_alloc as a kDLROCM tensor of the given
+ *   shape and dtype (DLPack codes: 0 int, 1 uint, 2 float); ownership of the memory moves to the
+ *   tensor, whose deleter frees it.  Blocks until the context's stream has finished, so the
+ *   consumer may read on any stream.
+ * ssdbox_dlpack_delete: calls the deleter of a tensor nobody consumed. */
+int ssdbox_dlpack_import(ssdbox_ctx *ctx, void *dl_managed_tensor, void **d_ptr, int64_t *n_elems,
+                         int32_t *dtype_code, int32_t *dtype_bits, int32_t *owned);
+int ssdbox_dlpack_export(ssdbox_ctx *ctx, void *d_ptr, int32_t ndim, const int64_t *shape,
+                         int32_t dtype_code, int32_t dtype_bits, void **dl_managed_tensor);
+int ssdbox_dlpack_delete(void *dl_managed_tensor);
 
 /* ---- anchor geometry: utils/anchor_utils.py:6-62 ----------------------------------- */
 /* Builds the feature-map geometry generate_anchors(config) iterates over, with the same

@@ -17,7 +17,7 @@ from face_detection_amd.utils import anchor_utils, box_utils        # noqa: E402
 
 
 def timeit(fn, reps=30):
-    for _ in range(3):
+    for _ in range(40):                 # first-use costs (allocations, code loading) stay outside
         fn()
     t0 = time.perf_counter()
     for _ in range(reps):
@@ -57,7 +57,7 @@ def main():
     out["compute_target_torch_ms"] = timeit(sync(lambda: box_utils.compute_target(anchors, d_gb, d_gl, 640.0)))
     out["decode_torch_ms"] = timeit(sync(lambda: box_utils.decode(anchors, d_locs)))
     out["compute_nms_torch_ms"] = timeit(sync(lambda: box_utils.compute_nms(d_cb, d_cs, 0.45, 1000)))
-    print(json.dumps({k: (round(v, 4) if isinstance(v, float) else v) for k, v in out.items()}))
+    print(json.dumps({k: (round(v, 4) if isinstance(v, float) else v) for k, v in out.items()}, default=str))
 
 
 if __name__ == "__main__":

@@ -233,41 +233,43 @@ SSD_DEV bool walk_list(MatchShared &sm, int n_list, unsigned lane, float max_siz
             // no lane of the wave can overlap these boxes: every IoU is +0, nothing to update
             if (__ballot(any) == 0ull) continue;
             touched = true;
-            // Evaluated without branches (an IoU of a non-overlapping pair is replaced by +0
-            // afterwards) so that the divisions overlap.
+            // Evaluated without branches so that the divisions overlap.  A lane without x overlap
+            // gets width 0; a row without y overlap gets a height <= 0 (never NaN: the anchor's
+            // corners are finite): the quotient is then <= 0 or NaN, where the reference has an
+            // IoU of +0, and neither can exceed a running best (>= 0) or count as a best anchor.
             float iou[U][R];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const float cw = vmin(iw[u], max_size);
+                const float cw = iw[u] > 0.0f ? vmin(iw[u], max_size) : 0.0f;
 #pragma unroll
                 for (int i = 0; i < R; ++i) {
                     const float ih = vmin(ay1[i], gb[u].w) - vmax(ay0[i], gb[u].y);
                     const float inter = cw * vmin(ih, max_size);
                     const float uni = (a_area[i] + garea[u]) - inter;
-                    const float q_iou = inter / uni;
-                    iou[u][i] = (iw[u] > 0.0f && ih > 0.0f) ? q_iou : 0.0f;
+                    iou[u][i] = inter / uni;
                 }
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if (u > 0 && qc[u] == qc[u - 1]) continue;     // the repeated box of a short step
                 const int gsel = LISTPOS ? qc[u] : sm.gidx[qc[u]];
-                float v = 0.0f;        // this lane's best IoU with the box, and its lowest row there
-                int vi = 0;
+                float v = 0.0f;        // this lane's best IoU with the box (a NaN operand is skipped)
 #pragma unroll
-                for (int i = R - 1; i >= 0; --i) {
+                for (int i = 0; i < R; ++i) {
                     if (iou[u][i] > best[i]) {
                         best[i] = iou[u][i];
                         sel[i] = gsel;
                     }
-                    if (iou[u][i] >= v) {
-                        v = iou[u][i];
-                        vi = i;
-                    }
+                    v = vmax(v, iou[u][i]);
                 }
                 // argmax over anchors (:70): only a lane at or above the tile's best IoU so far
                 // for this box can change it; wave maximum, then the lowest anchor holding it
                 if (__ballot(v > 0.0f && v >= cur[u]) != 0ull) {
+                    int vi = 0;        // the lane's lowest row holding v
+#pragma unroll
+                    for (int i = R - 1; i > 0; --i)
+                        if (iou[u][i] == v) vi = i;
+                    if (iou[u][0] == v) vi = 0;
                     const float mx = wave_max_nonneg(v);
                     const int av = a0 + vi * a_step;
                     const int a_src = (int)wave_min_u32((v == mx) ? (uint32_t)av : 0xFFFFFFFFu);

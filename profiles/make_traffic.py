@@ -22,7 +22,7 @@ for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recur
         if m and row["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
             acc[m.group(1)][row["Counter_Name"]].append(float(row["Counter_Value"]))
 res = {}
-for short, name in (("match", "match"), ("select", "select_rows6")):
+for short, name in (("match", "match_geom"), ("select", "select_rows6")):
     c = acc.get(name)
     if not c or "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
         continue

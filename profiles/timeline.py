@@ -16,11 +16,11 @@ for path in glob.glob(os.path.join(sys.argv[1], "**", "*kernel_trace.csv"), recu
 rows.sort()
 names = [n for _, _, n in rows]
 # steady part: from the middle third of the match kernels to the end
-starts = [i for i, n in enumerate(names) if n == "match_kernel"]
+starts = [i for i, n in enumerate(names) if n == "match_geom_kernel"]
 lo, hi = starts[len(starts) // 3], starts[-1]
 part = rows[lo:hi]
 span = part[-1][0] - part[0][0]
-n_steps = len([1 for _, _, n in part if n == "match_kernel"])
+n_steps = len([1 for _, _, n in part if n == "match_geom_kernel"])
 print("steps in window: %d   span per step: %.2f us" % (n_steps, span / n_steps / 1e3))
 dur = {}
 for s, e, n in part:

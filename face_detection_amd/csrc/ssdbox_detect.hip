@@ -53,12 +53,12 @@ SSD_DEV float softmax_face(float l0, float l1)
 // Head rows are 24 bytes [bg, face, tx, ty, tw, th]; read as a float4 stream, the face score
 // of anchor 2q sits in .y of float4 3q and that of anchor 2q+1 in .w of float4 3q+1.  A wave
 // owns 384 consecutive float4 (256 anchors): six fully coalesced 1-KiB loads.
-// The grid is persistent: at most kSelWgsPerCu workgroups per CU, every wave walking the
-// (image, segment) items with a grid stride while the loads of its next item are in flight.
-// Half of the CU's wave slots stay free, so the per-image kernels of other streams' batches
-// (large workgroups) find room next to this one; long-lived waves with twelve loads per lane
-// in flight read at the same rate as a full grid does.
-constexpr int kSelWgsPerCu = 4;
+// A wave takes (image, segment) items with a grid stride, the loads of its next item in flight
+// while it works on the current one.  The grid is capped at kSelWgsPerCu workgroups per CU; at the
+// benchmark size (12 768 items) that is one item per wave.  A small persistent grid (4 workgroups
+// per CU, three items per wave) was measured and is slower, alone (15.2 against 13.3 us) and with
+// four batches in flight (decode+NMS 1.38e6 against 1.48e6 images/s).
+constexpr int kSelWgsPerCu = 64;
 
 template <bool LOGITS>
 __global__ __launch_bounds__(kSelBlock) void select_rows6_kernel(const float4 *__restrict__ y, int n,

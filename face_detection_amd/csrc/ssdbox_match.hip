@@ -613,15 +613,41 @@ __global__ __launch_bounds__(kBlock) void force_kernel(const MatchArgs p)
         const int a = s_anc[g];
         const float4 box = gt[g];
         const float label = p.gt_labels[(long long)img * p.gmax + g];
-        bool later = false;            // a later box claims the same anchor: it wins
-        for (int g2 = g + 1; g2 < G; ++g2) {
-            if (s_anc[g2] == a) {
-                later = true;
-                break;
+        // The anchor is requested before the scan below, from the launch's own layer table and the
+        // anchor-column table: one round trip to memory.
+        float4 anc;
+        if (GEOM) {
+            int m = 0;                         // anchor_base grows with the layer
+#pragma unroll
+            for (int l = 1; l < SSDBOX_MAX_LAYERS; ++l) m += (l < p.n_layers && a >= p.ml[l].anchor_base) ? 1 : 0;
+            int base = 0, row_anchors = 1, col_off = 0, cy_off = 0;
+#pragma unroll
+            for (int l = 0; l < SSDBOX_MAX_LAYERS; ++l) {      // (scalar registers cannot be indexed by a lane)
+                if (l == m) {
+                    base = p.ml[l].anchor_base;
+                    row_anchors = p.ml[l].row_anchors;
+                    col_off = p.ml[l].col_off;
+                    cy_off = p.ml[l].cy_off;
+                }
             }
+            const int r = a - base;
+            const int i = r / row_anchors;
+            const float4 col = p.col_tab[col_off + (r - i * row_anchors)];
+            anc = make_float4(col.x, p.cy_tab[cy_off + i], col.y, col.z);
+        } else {
+            anc = p.anchors[a];
+        }
+        // A later box that claims the same anchor wins it.  No early exit: the loads of the scan
+        // are independent of each other and stay in flight together.
+        bool later = false;
+        for (int g2 = 0; g2 < G; g2 += 8) {
+            int other[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) other[u] = s_anc[min(g2 + u, G - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) later = later || (g2 + u > g && g2 + u < G && other[u] == a);
         }
         if (later) continue;
-        const float4 anc = GEOM ? geom_anchor(p.geom, p.cx_tab, p.cy_tab, a) : p.anchors[a];
         const float conf = (1.0f < p.thr) ? 0.0f : label;
         const float4 tgt = encode_one(anc, box, 0.1f, 0.2f);
         store_target<YTRUE, true>(p, (long long)img * p.num_anchors + a, 0u, conf, tgt, g, 1.0f);

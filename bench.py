@@ -477,9 +477,11 @@ def main():
     value = images / elapsed
 
     # the two halves on their own (same protocol), for the per-half figures of the metric
+    # (auxiliary figures: at least 200 steps each, so that a short --steps run reads the same rates)
     nslots = len(wl.slots)
-    t_match = timed_loop(torch, dist, world, lambda i: wl.match(wl.slots[i % nslots]), args.steps, 5)
-    t_det = timed_loop(torch, dist, world, lambda i: wl.detect(wl.slots[i % nslots]), args.steps, 5)
+    half_steps = max(args.steps, 200)
+    t_match = timed_loop(torch, dist, world, lambda i: wl.match(wl.slots[i % nslots]), half_steps, 20)
+    t_det = timed_loop(torch, dist, world, lambda i: wl.detect(wl.slots[i % nslots]), half_steps, 20)
 
     # evaluation.py:67 runs the same post-processing with threshold 0: every anchor is a candidate
     thr = args.score_thr
@@ -587,8 +589,9 @@ def main():
                 "batch_per_gpu": args.batch, "anchors": wl.A, "gt_total": int(wl.gt_counts.sum()),
                 "kept_total": n_keep, "batches_in_flight": nslots, "stream_priority": args.stream_priority, "parallelism": "image-sharded x%d" % world,
             },
-            "match_encode_images_per_s": args.batch * args.steps * world / t_match,
-            "decode_nms_images_per_s": args.batch * args.steps * world / t_det,
+            "match_encode_images_per_s": args.batch * half_steps * world / t_match,
+            "decode_nms_images_per_s": args.batch * half_steps * world / t_det,
+            "half_steps": half_steps,
             "decode_nms_thr0_images_per_s": args.batch * n_det0 * world / t_det0,
             "kernel_us_thr0": {k: round(v, 2) for k, v in stages0.items()
                                if k in ("select", "prune", "topk", "nms_mask", "nms_scan")},
@@ -603,8 +606,8 @@ def main():
                 "algorithmic_bytes_per_launch": half_bytes[dominant],
                 # the halves as they run in the timed loops (all their kernels, batches in flight):
                 # algorithmic bytes of the half x its images per second / peak
-                "match_encode_half_frac": match_bytes / args.batch * (args.batch * args.steps / t_match) / 1e9 / HBM_PEAK_GBS,
-                "decode_nms_half_frac": detect_bytes / args.batch * (args.batch * args.steps / t_det) / 1e9 / HBM_PEAK_GBS,
+                "match_encode_half_frac": match_bytes / args.batch * (args.batch * half_steps / t_match) / 1e9 / HBM_PEAK_GBS,
+                "decode_nms_half_frac": detect_bytes / args.batch * (args.batch * half_steps / t_det) / 1e9 / HBM_PEAK_GBS,
             },
             "roofline_kernels": {k: {"achieved_GBs": v, "frac": v / HBM_PEAK_GBS} for k, v in per_kernel.items()},
         }

@@ -536,6 +536,7 @@ def main():
     if rank == 0:
         stages = stage_times(wl, min(args.steps, 100))
         match_bytes, detect_bytes, n_keep = wl.algorithmic_bytes()
+        gt_total = int(wl.gt_counts.sum())                # of the reported batch, before other batches load
         lat = single_batch_latency(wl)
         lat1 = single_image_latency(wl)
         pcie = pcie_times(wl)
@@ -563,6 +564,9 @@ def main():
                       "match_encode_images_per_s": args.batch * n_s * world / t_sm}
 
     if rank == 0:
+        KERNEL_SYMBOL = {"match": "match_geom_kernel", "force": "force_kernel", "select": "select_rows6_kernel",
+                         "prune": "cand_prune_kernel", "topk": "topk_sort_kernel", "nms_mask": "nms_mask_kernel",
+                         "nms_scan": "nms_scan_kernel"}
         # every kernel of a half is priced against the algorithmic bytes of that half
         half_bytes = {"match": match_bytes, "force": match_bytes, "select": detect_bytes, "prune": detect_bytes,
                       "topk": detect_bytes, "nms_mask": detect_bytes, "nms_scan": detect_bytes}
@@ -586,7 +590,7 @@ def main():
                             "batch %d @%dx%d, A=%d, <=%d GT/image%s, score_thr %.2f, nms 0.45, "
                             "limit 1000" % (args.batch, args.size, args.size, wl.A, args.gmax,
                                             " (all 256)" if args.stress else "", args.score_thr),
-                "batch_per_gpu": args.batch, "anchors": wl.A, "gt_total": int(wl.gt_counts.sum()),
+                "batch_per_gpu": args.batch, "anchors": wl.A, "gt_total": gt_total,
                 "kept_total": n_keep, "batches_in_flight": nslots, "stream_priority": args.stream_priority, "parallelism": "image-sharded x%d" % world,
             },
             "match_encode_images_per_s": args.batch * half_steps * world / t_match,
@@ -600,7 +604,7 @@ def main():
             "ssd_loss_fwd_bwd_ms": t_loss / n_loss * 1e3,
             "kernel_us": {k: round(v, 2) for k, v in stages.items()},
             "roofline": {
-                "bound": "hbm", "kernel": dominant + "_kernel",
+                "bound": "hbm", "kernel": KERNEL_SYMBOL[dominant],
                 "achieved": per_kernel[dominant], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": per_kernel[dominant] / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": half_bytes[dominant],

@@ -316,7 +316,9 @@ SSD_DEV bool above_bucket(const Bucket &b, u64 key, float lo, float scale)
 
 // Value of `x` in lane (lane ^ J), J a power of two below 64: quad permutes for 1 and 2, a
 // swizzle (xor inside each half wave, no address register) for 4..16, a permute across the
-// halves for 32.
+// halves for 32.  (The swizzles run in the LDS pipeline next to the VALU, which is what bounds
+// the network with 16 waves on one CU: row shifts for 4 and 8 and the gfx950 row / half-wave
+// swaps for 16 and 32 instead measured 4.4 us against 3.9 us for the sort.)
 template <int J>
 SSD_DEV unsigned int xor_lane(unsigned int x)
 {
@@ -409,6 +411,14 @@ __global__ __launch_bounds__(kTopkBlock) void topk_sort_kernel(const TopkArgs p)
     const u64 *cand = p.cand + (long long)img * nseg * kSeg;
     const int *segc = p.seg_count + (long long)img * nseg;
     const float lo = p.lo, scale = p.scale;
+#ifdef SSD_EXP_STAMPS              // timing experiment (profiles/topk_stamps.py): phase stamps of image 0
+    unsigned long long st[8];
+    int sti = 0;
+#define SSD_STAMP() st[sti++] = wall_clock64()
+#else
+#define SSD_STAMP()
+#endif
+    SSD_STAMP();
 
     // ---- total number of candidates, and where this thread's segments (t, t + 1024, ...) go
     // if everything is staged: the order of the staged keys does not matter
@@ -436,6 +446,7 @@ __global__ __launch_bounds__(kTopkBlock) void topk_sort_kernel(const TopkArgs p)
     const int K = min(n, p.limit);
     if (t == 0) p.keff[img] = K;
     if (n == 0) return;
+    SSD_STAMP();
 
     Bucket bk;
     bk.use_lin = 0;
@@ -564,6 +575,7 @@ __global__ __launch_bounds__(kTopkBlock) void topk_sort_kernel(const TopkArgs p)
         // after the last bit field the keys (unique) are fully resolved: bucket == 1 == k_rem
     }
 
+    SSD_STAMP();
     // ---- the keys to sort: everything staged, or exactly the K largest
     u64 key = 0ull;                    // padding ranks below every real key
     int m_sort;
@@ -595,12 +607,14 @@ __global__ __launch_bounds__(kTopkBlock) void topk_sort_kernel(const TopkArgs p)
         __syncthreads();               // s_xchg is reused by the sort
     }
 
+    SSD_STAMP();
     // ---- bitonic sort, descending, one key per thread
     int P = 64;
     while (P < m_sort) P <<= 1;
     int phase = 0;
     SortStep<2, 1>::run(key, t, s_xchg, phase, P);
 
+    SSD_STAMP();
     // ---- rank t < K: decode / gather its box
     if (t < K) {
         const uint32_t idx = 0xFFFFFFFFu - (uint32_t)key;
@@ -624,6 +638,15 @@ __global__ __launch_bounds__(kTopkBlock) void topk_sort_kernel(const TopkArgs p)
         p.sscores[o] = score;
         p.sidx[o] = (int)idx;
     }
+#ifdef SSD_EXP_STAMPS
+    __builtin_amdgcn_s_waitcnt(0);
+    SSD_STAMP();
+    if (img == 0 && t == 0)
+        printf("topk img0 n=%d K=%d m_lds=%d  count %.2f  stage+select %.2f  extract %.2f  sort %.2f  gather+store %.2f us\n",
+               n, K, m_lds, (st[1] - st[0]) * 0.01, (st[2] - st[1]) * 0.01, (st[3] - st[2]) * 0.01,
+               (st[4] - st[3]) * 0.01, (st[5] - st[4]) * 0.01);
+#endif
+#undef SSD_STAMP
 }
 
 // ---------------------------------------------------------------------------- NMS mask

@@ -44,11 +44,20 @@ constexpr int kDLCPU = 1, kDLCUDAHost = 3, kDLROCM = 10, kDLROCMHost = 11;
 
 int ensure_staging(ssdbox_ctx *ctx)
 {
-    if (ctx->stage[0] != nullptr) return SSDBOX_OK;
+    if (ctx->stage[0] != nullptr && ctx->stage[1] != nullptr) return SSDBOX_OK;
     for (int i = 0; i < 2; ++i) {
-        hipError_t e = hipHostMalloc(&ctx->stage[i], kStageChunk, hipHostMallocDefault);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->stage_ev[i], hipEventDisableTiming);
+        hipError_t e = hipSuccess;
+        if (ctx->stage[i] == nullptr) e = hipHostMalloc(&ctx->stage[i], kStageChunk, hipHostMallocDefault);
+        if (e == hipSuccess && ctx->stage_ev[i] == nullptr)
+            e = hipEventCreateWithFlags(&ctx->stage_ev[i], hipEventDisableTiming);
         if (e != hipSuccess) {
+            // all or nothing: a later call starts over
+            for (int k = 0; k < 2; ++k) {
+                if (ctx->stage[k] != nullptr) (void)hipHostFree(ctx->stage[k]);
+                if (ctx->stage_ev[k] != nullptr) (void)hipEventDestroy(ctx->stage_ev[k]);
+                ctx->stage[k] = nullptr;
+                ctx->stage_ev[k] = nullptr;
+            }
             set_error("pinned staging allocation failed: %s", hipGetErrorString(e));
             return SSDBOX_ERR_NOMEM;
         }
@@ -72,6 +81,7 @@ int buf_alloc_impl(ssdbox_ctx *ctx, size_t bytes, void **d_out)
 {
     *d_out = nullptr;
     const size_t want = bytes ? (bytes + 255) / 256 * 256 : 256;
+    ctx->buf_live.reserve(ctx->buf_live.size() + 1);       // may throw here, not after the allocation
     // a freed buffer of this size, if the context kept one (reuse is in stream order: whoever
     // freed it had enqueued its last use on this context's stream)
     for (size_t i = 0; i < ctx->buf_free.size(); ++i) {
@@ -239,6 +249,7 @@ extern "C" int ssdbox_buf_free(ssdbox_ctx *ctx, void *d_ptr)
     if (d_ptr == nullptr) return SSDBOX_OK;
     DeviceGuard guard(ctx->device);
     SSD_NOTHROW_BEGIN
+    ctx->buf_free.reserve(ctx->buf_free.size() + 1);
     const size_t bytes = take_live(ctx, d_ptr);
     SSD_REQUIRE(bytes != 0, "ssdbox_buf_free: %p was not allocated by this context (or was exported)", d_ptr);
     if (ctx->buf_cached + bytes <= kCacheLimit) {

@@ -152,6 +152,8 @@ def default_context(device=None, torch_stream=None):
 _DL_CODE = {"i": 0, "u": 1, "f": 2}
 _capsule_get = ctypes.pythonapi.PyCapsule_GetPointer
 _capsule_get.restype, _capsule_get.argtypes = ctypes.c_void_p, [ctypes.py_object, ctypes.c_char_p]
+_capsule_valid = ctypes.pythonapi.PyCapsule_IsValid
+_capsule_valid.restype, _capsule_valid.argtypes = ctypes.c_int, [ctypes.py_object, ctypes.c_char_p]
 _capsule_new = ctypes.pythonapi.PyCapsule_New
 _capsule_new.restype, _capsule_new.argtypes = ctypes.py_object, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p]
 
@@ -552,9 +554,17 @@ class Session:
         if family == "tf":
             import tensorflow as tf
             if isinstance(arr, DevArray):
+                # the capsule owns the memory from here on; while it is alive and unconsumed the
+                # memory is still valid, so the host copy of the fallback is taken before it goes
+                src = arr if (arr._root is None and arr._owned) else arr.clone()
+                capsule = src.to_dlpack()
                 try:
-                    return tf.experimental.dlpack.from_dlpack(arr.to_dlpack())
+                    return tf.experimental.dlpack.from_dlpack(capsule)
                 except Exception:
-                    return tf.convert_to_tensor(arr.numpy())
+                    if not _capsule_valid(capsule, b"dltensor"):
+                        raise                    # consumed before it failed: the memory is TensorFlow's
+                    host = src.numpy()
+                    del capsule
+                    return tf.convert_to_tensor(host)
             return tf.convert_to_tensor(arr.cpu().numpy())
         return self.host(arr)

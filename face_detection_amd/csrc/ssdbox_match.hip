@@ -89,6 +89,7 @@ struct MatchShared {
     int wcnt[2][kBlock / 64];
     float ext[4][kBlock / 64];
     float4 lane_const[kBlock];     // per thread: what only the final encode of a row needs
+    float2 shape_wh[SSDBOX_MAX_BOXES_PER_CELL];   // the layer's box shapes
 };
 
 // Loads and stores at a wave-uniform base plus a 32-bit per-lane byte offset: one address
@@ -335,8 +336,7 @@ SSD_DEV void geom_tile(const MatchArgs &p, MatchShared &sm, const MatchLayer &L)
     const float4 *cols = p.col_tab + L.col_off;               // padded by a tile per layer
     const float4 col = ld_off<float4>(cols, c * 16u);
     // the layer's box shapes are the (w, h) of its first n_box anchor columns
-    const unsigned k_item = n_box == 1u ? 0u : t - __umulhi(t, L.nbox_magic) * n_box;
-    const float4 shape_item = ld_off<float4>(cols, k_item * 16u);
+    const float4 shape_mine = ld_off<float4>(cols, min(t, n_box - 1u) * 16u);
     float cy_mine = 0.0f;
     if ((int)t < tile_rows) cy_mine = p.cy_tab[L.cy_off + min(t_r0 + (int)t, L.fm_h - 1)];
     const float acx = col.x, aw = col.y, ah = col.z;
@@ -353,6 +353,7 @@ SSD_DEV void geom_tile(const MatchArgs &p, MatchShared &sm, const MatchLayer &L)
     const float ahw = aw / 2.0f, ahh = ah / 2.0f;
     const float ax0 = acx - ahw, ax1 = acx + ahw;            // transform_center_to_corner, :177-179
     const float a_w = clip0(ax1 - ax0, p.max_size);
+    if (t < n_box) sm.shape_wh[t] = make_float2(shape_mine.y, shape_mine.z);
     if (!MULTI) {
         // What only the final encode of a row needs waits in LDS (read back by the same thread),
         // not in registers that would stay occupied during the walk over the boxes: the
@@ -386,7 +387,7 @@ SSD_DEV void geom_tile(const MatchArgs &p, MatchShared &sm, const MatchLayer &L)
                 if (!MULTI) {
                     const float dy = (b0.y + b0.w) / 2.0f - cy_mine;
 #pragma unroll 1
-                    for (unsigned kk = 0; kk < n_box; ++kk) s_ty0[t * n_box + kk] = dy / (cols[kk].z * 0.1f);
+                    for (unsigned kk = 0; kk < n_box; ++kk) s_ty0[t * n_box + kk] = dy / (sm.shape_wh[kk].y * 0.1f);
                 }
             }
         }
@@ -397,11 +398,11 @@ SSD_DEV void geom_tile(const MatchArgs &p, MatchShared &sm, const MatchLayer &L)
             for (unsigned item = t; item < n_items; item += kBlock) {
                 const unsigned q = n_box == 1u ? item : __umulhi(item, L.nbox_magic);
                 const unsigned kk = item - q * n_box;
-                const float4 sh = (item == t) ? shape_item : cols[kk];
+                const float2 sh = sm.shape_wh[kk];
                 const float4 bx = (int)q < n_list ? sm.box[q] : b0;
                 const unsigned slot = (int)q < n_list ? q : (unsigned)kListCap;
                 s_lwh[slot * n_box + kk] =
-                    make_float2(ssd_logf((bx.z - bx.x) / sh.y) / 0.2f, ssd_logf((bx.w - bx.y) / sh.z) / 0.2f);
+                    make_float2(ssd_logf((bx.z - bx.x) / sh.x) / 0.2f, ssd_logf((bx.w - bx.y) / sh.y) / 0.2f);
             }
         }
         if (!MULTI || g0 == 0) __syncthreads();

@@ -152,3 +152,33 @@ def test_fuzz_ssd_loss(fda, seed):
     np.testing.assert_array_equal(keep, c_keep, err_msg=repr((B, A, kw)))
     np.testing.assert_allclose(total, c_total, rtol=1e-6, equal_nan=True, err_msg=repr((B, A, kw)))
     np.testing.assert_array_equal(bits(grad), bits(c_grad), err_msg=repr((B, A, kw)))
+
+
+@pytest.mark.parametrize("gmax", [256, 300])
+def test_match_encode_widest_cells_and_tallest_tiles(fda, gmax):
+    """Fifteen box shapes per cell (the most the geometry takes) on a 640-row image: the largest
+    per-tile tables the match kernel builds, with one full list of boxes (256) and with more than
+    one list (300: the chunked walk)."""
+    rng = np.random.default_rng(99)
+    ratios = [round(0.4 + 0.2 * i, 2) for i in range(14)] + [1.0]          # 14 + the 1.0 pair = 16 > limit
+    ratios = sorted(set(ratios))[:14]                                       # 13 plain + 1.0 (two boxes) = 15
+    assert 1.0 in ratios
+    cfg = {'img_height': 640, 'img_width': 96, 'image_size': (640, 96), 'offsets': 0.5, 'n_classes': 1,
+           'scales': [0.05, 0.2, 0.5], 'aspect_ratios_per_layer': [ratios, ratios[:3]],
+           'two_boxes_for_ar1': True, 'steps': [4, 32], 'variances': [0.1, 0.2]}
+    anchors_np = O.generate_anchors(cfg)
+    grid = fda.anchor_utils.generate_anchors(cfg)
+    np.testing.assert_array_equal(bits(np.asarray(grid)), bits(anchors_np))
+    boxes, labels, counts = random_ground_truth(rng, 2, gmax)
+    counts[0] = gmax
+    boxes0, labels0, _ = random_ground_truth(rng, 1, gmax)
+    boxes[0], labels[0] = boxes0[0], labels0[0]
+    conf, locs, midx, miou = fda.match_encode_batch(grid, boxes, counts, labels, 640.0, 0.5, return_match=True)
+    for b in range(2):
+        g = counts[b]
+        c_conf, c_locs, c_idx, c_iou, _ = C.compute_target(anchors_np, boxes[b, :g], labels[b, :g], 640.0, 0.5,
+                                                           details=True)
+        np.testing.assert_array_equal(np.asarray(midx[b]), c_idx)
+        np.testing.assert_array_equal(bits(miou[b]), bits(c_iou))
+        np.testing.assert_array_equal(bits(conf[b]), bits(c_conf))
+        np.testing.assert_array_equal(bits(locs[b]), bits(c_locs))

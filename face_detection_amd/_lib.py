@@ -21,7 +21,7 @@ ERR_UNSUPPORTED = -4
 NUM_STAGES = 10
 STAGE_NAMES = ("match", "force", "select", "topk", "nms_mask", "nms_scan", "elementwise", "shapes",
                "loss", "prune")
-MAX_NMS_LIMIT = 1024
+MAX_NMS_LIMIT = 4096
 MAX_GT = 4096
 MAX_LAYERS = 8
 STATIC_SCRATCH_BYTES = 4 << 20

@@ -31,7 +31,9 @@ typedef unsigned long long u64;
 
 constexpr int kSeg = 256;                  // candidate slots per segment = anchors per wave
 constexpr int kSelBlock = 256;
-constexpr int kLimit = SSDBOX_MAX_NMS_LIMIT;
+constexpr int kLimit = 1024;                // ranked boxes per image on the fast path (mask + scan)
+constexpr int kBigLimit = SSDBOX_MAX_NMS_LIMIT;   // ... on the general path (sequential greedy loop)
+constexpr int kBigRanks = kBigLimit / 1024;
 constexpr int kWords = kLimit / 64;
 constexpr int kCap = 8192;                 // keys the top-k kernel stages in LDS
 constexpr int kBucketMax = 256;            // bucket size resolved by direct ranking
@@ -393,11 +395,17 @@ SSD_DEV void for_each_candidate(const u64 *__restrict__ cand, const int *__restr
     }
 }
 
+// RANKS: ranked boxes per thread.  1: up to 1024 ranks, sorted in registers (the path every
+// caller of the reference takes: limit 1000 at inference.py:60, 200 by default).  kBigRanks: up to
+// kBigLimit ranks, sorted in LDS.
+template <int RANKS>
 __global__ __launch_bounds__(kTopkBlock) void topk_sort_kernel(const TopkArgs p)
 {
+    constexpr int kSortCap = kTopkBlock * RANKS;          // keys the final sort takes
     __shared__ u64 s_keys[kCap];
     __shared__ unsigned int s_hist[kBins];
     __shared__ u64 s_xchg[2][kTopkBlock];
+    __shared__ u64 s_big[RANKS > 1 ? kSortCap : 1];
     __shared__ u64 s_bucket[kBucketMax];
     __shared__ unsigned int s_wtot[kTopkBlock / 64];
     __shared__ unsigned int s_sel[3];
@@ -513,7 +521,7 @@ __global__ __launch_bounds__(kTopkBlock) void topk_sort_kernel(const TopkArgs p)
             m_lds = s_count;           // == n_above + bucket
             in_lds = true;
         }
-        if (in_lds && (m_lds <= kTopkBlock || bucket <= kBucketMax || bucket == k_rem)) break;
+        if (in_lds && (m_lds <= kSortCap || bucket <= kBucketMax || bucket == k_rem)) break;
 
         // ---- one histogram pass over the current bucket
         const int dg = next_digit++;
@@ -579,11 +587,15 @@ __global__ __launch_bounds__(kTopkBlock) void topk_sort_kernel(const TopkArgs p)
     // ---- the keys to sort: everything staged, or exactly the K largest
     u64 key = 0ull;                    // padding ranks below every real key
     int m_sort;
-    if (m_lds <= kTopkBlock) {
+    u64 *s_out = RANKS > 1 ? s_big : s_xchg[0];
+    if (m_lds <= kSortCap) {
         m_sort = m_lds;
-        if (t < m_lds) key = s_keys[t];
+        if (RANKS == 1) {
+            if (t < m_lds) key = s_keys[t];
+        } else {
+            for (int i = t; i < m_lds; i += kTopkBlock) s_out[i] = s_keys[i];
+        }
     } else {
-        u64 *s_out = s_xchg[0];
         const bool whole_bucket = (bucket == k_rem);
         for (int i = t; i < m_lds; i += kTopkBlock) {
             const u64 kk = s_keys[i];
@@ -603,20 +615,47 @@ __global__ __launch_bounds__(kTopkBlock) void topk_sort_kernel(const TopkArgs p)
         }
         __syncthreads();
         m_sort = K;                    // == s_count2
-        if (t < K) key = s_out[t];
-        __syncthreads();               // s_xchg is reused by the sort
+        if (RANKS == 1) {
+            if (t < K) key = s_out[t];
+            __syncthreads();           // s_xchg is reused by the sort
+        }
     }
 
     SSD_STAMP();
-    // ---- bitonic sort, descending, one key per thread
     int P = 64;
     while (P < m_sort) P <<= 1;
-    int phase = 0;
-    SortStep<2, 1>::run(key, t, s_xchg, phase, P);
+    if (RANKS == 1) {
+        // ---- bitonic sort, descending, one key per thread
+        int phase = 0;
+        SortStep<2, 1>::run(key, t, s_xchg, phase, P);
+    } else {
+        // ---- bitonic sort, descending, in LDS: every step one pass over the P / 2 pairs
+        for (int i = m_sort + t; i < P; i += kTopkBlock) s_out[i] = 0ull;
+        __syncthreads();
+        for (int kb = 2; kb <= P; kb <<= 1) {
+            for (int j = kb >> 1; j > 0; j >>= 1) {
+                for (int i = t; i < P / 2; i += kTopkBlock) {
+                    const int a = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+                    const int b = a | j;
+                    const u64 ka = s_out[a], kbv = s_out[b];
+                    const bool descending = (a & kb) == 0;
+                    if (descending ? (ka < kbv) : (ka > kbv)) {
+                        s_out[a] = kbv;
+                        s_out[b] = ka;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
 
     SSD_STAMP();
-    // ---- rank t < K: decode / gather its box
-    if (t < K) {
+    // ---- ranks t, t + 1024, ... below K: decode / gather their boxes
+#pragma unroll
+    for (int q = 0; q < RANKS; ++q) {
+        const int r = q * kTopkBlock + t;
+        if (r >= K) continue;
+        if (RANKS > 1) key = s_out[r];
         const uint32_t idx = 0xFFFFFFFFu - (uint32_t)key;
         float4 box;
         float score;
@@ -633,7 +672,7 @@ __global__ __launch_bounds__(kTopkBlock) void topk_sort_kernel(const TopkArgs p)
                                    : p.src.anchors[idx];
             box = decode_one(anc, make_float4(lxy.x, lxy.y, lwh.x, lwh.y), 0.1f, 0.2f);
         }
-        const long long o = (long long)img * kLimit + t;
+        const long long o = (long long)img * kSortCap + r;
         p.sboxes[o] = box;
         p.sscores[o] = score;
         p.sidx[o] = (int)idx;
@@ -865,8 +904,110 @@ __global__ __launch_bounds__(kLimit) void nms_scan_kernel(
     if (t == 0) count[img] = total;
 }
 
+// ------------------------------------------------- NMS, general path (more than 1024 ranks)
+// compute_nms's loop as it is written (utils/box_utils.py:205-222): the first box not yet
+// suppressed is kept and suppresses every later box whose IoU with it is not <= thr; one
+// workgroup per image keeps the ranked boxes in LDS and walks the ranks in order.  No caller of
+// the reference reaches this path (limit is 1000 at inference.py:60 and 200 by default): it
+// exists so that any limit up to kBigLimit gives the reference's result, not for speed (one
+// barrier per kept box).
+__global__ __launch_bounds__(kTopkBlock) void nms_greedy_big_kernel(
+    const float4 *__restrict__ sboxes, const float *__restrict__ sscores, const int *__restrict__ sidx,
+    const int *__restrict__ keff, float thr, int limit, const float *__restrict__ img_wh,
+    float *__restrict__ dets, int *__restrict__ keep_idx, int *__restrict__ count)
+{
+    __shared__ float4 s_box[kBigLimit];
+    __shared__ float s_area[kBigLimit];
+    __shared__ u64 s_removed[kBigLimit / 64];
+    __shared__ u64 s_kept[kBigLimit / 64];
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int img = blockIdx.x;
+    const int K = keff[img];
+    const long long base = (long long)img * kBigLimit;
+    for (int r = t; r < K; r += kTopkBlock) {
+        const float4 b = sboxes[base + r];
+        s_box[r] = b;
+        s_area[r] = box_area(b, kNmsMaxSize);
+    }
+    if (t < kBigLimit / 64) {
+        s_removed[t] = 0ull;
+        s_kept[t] = 0ull;
+    }
+    __syncthreads();
+    const bool zero_suppresses = !(0.0f <= thr);
+    for (int i = 0; i < K; ++i) {
+        // (uniform: every thread reads the same word, written before the last barrier)
+        if ((s_removed[i >> 6] >> (i & 63)) & 1ull) continue;
+        if (t == 0) s_kept[i >> 6] |= 1ull << (i & 63);
+        const float4 ib = s_box[i];
+        const float iarea = s_area[i];
+        for (int j0 = i + 1; j0 < K; j0 += kTopkBlock) {
+            const int j = j0 + t;
+            bool sup = false;
+            if (j < K) {
+                const float4 jb = s_box[j];
+                // compute_iou(boxes_a = earlier box, boxes_b = later box), utils/box_utils.py:35-42
+                const float iw = vmin(ib.z, jb.z) - vmax(ib.x, jb.x);
+                const float ih = vmin(ib.w, jb.w) - vmax(ib.y, jb.y);
+                const float asum = iarea + s_area[j];
+                if (iw > 0.0f && ih > 0.0f) {
+                    const float inter = vmin(iw, kNmsMaxSize) * vmin(ih, kNmsMaxSize);
+                    const float iou = inter / (asum - inter);
+                    sup = !(iou <= thr);
+                } else {
+                    // intersection 0: IoU is +0 over a positive union, NaN over a zero one
+                    sup = (asum > 0.0f) ? zero_suppresses : true;
+                }
+            }
+            // a wave's 64 boxes j0 + 64 w .. lie in at most two words of the bit set
+            const u64 bal = __ballot(sup);
+            if (bal != 0ull && lane == 0) {
+                const int first = j0 + (t & ~63);
+                const int sh = first & 63;
+                atomicOr(&s_removed[first >> 6], bal << sh);
+                if (sh != 0 && (first >> 6) + 1 < kBigLimit / 64) atomicOr(&s_removed[(first >> 6) + 1], bal >> (64 - sh));
+            }
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+
+    // kept boxes in rank order; the rest of the `limit` slots cleared (as the scan kernel does)
+    int total = 0;
+    for (int w = 0; w < kBigLimit / 64; ++w) total += __popcll(s_kept[w]);
+    const float W = img_wh ? img_wh[2 * img] : 1.0f;
+    const float H = img_wh ? img_wh[2 * img + 1] : 1.0f;
+    for (int r = t; r < limit; r += kTopkBlock) {
+        if (r < K && ((s_kept[r >> 6] >> (r & 63)) & 1ull)) {
+            int pos = __popcll(s_kept[r >> 6] & ((1ull << (r & 63)) - 1ull));
+            for (int w = 0; w < (r >> 6); ++w) pos += __popcll(s_kept[w]);
+            keep_idx[(long long)img * limit + pos] = sidx[base + r];
+            if (dets != nullptr) {
+                // clip to [0,1], scale to the original image, [class, score, box] rows
+                // (reference inference.py:73-83)
+                const float4 b = s_box[r];
+                float2 *d = reinterpret_cast<float2 *>(dets + ((long long)img * limit + pos) * 6);
+                d[0] = make_float2(1.0f, sscores[base + r]);
+                d[1] = make_float2(clip0(b.x, 1.0f) * W, clip0(b.y, 1.0f) * H);
+                d[2] = make_float2(clip0(b.z, 1.0f) * W, clip0(b.w, 1.0f) * H);
+            }
+        }
+        if (r >= total) {
+            keep_idx[(long long)img * limit + r] = -1;
+            if (dets != nullptr) {
+                float2 *d = reinterpret_cast<float2 *>(dets + ((long long)img * limit + r) * 6);
+                d[0] = make_float2(0.f, 0.f);
+                d[1] = make_float2(0.f, 0.f);
+                d[2] = make_float2(0.f, 0.f);
+            }
+        }
+    }
+    if (t == 0) count[img] = total;
+}
+
 // -------------------------------------------------------------------------------- host
-int ensure_detect_scratch(ssdbox_ctx *ctx, int batch, long long nseg)
+int ensure_detect_scratch(ssdbox_ctx *ctx, int batch, long long nseg, int rank_cap)
 {
     int rc = ensure_buffer((void **)&ctx->cand, &ctx->cand_cap, (size_t)batch * (size_t)nseg * kSeg,
                            sizeof(u64), false, ctx->stream);
@@ -877,7 +1018,8 @@ int ensure_detect_scratch(ssdbox_ctx *ctx, int batch, long long nseg)
     rc = ensure_buffer((void **)&ctx->cand_hist, &ctx->hist_cap, (size_t)batch * kBins, sizeof(unsigned int),
                        false, ctx->stream);
     if (rc != SSDBOX_OK) return rc;
-    if ((size_t)batch > ctx->det_cap) {
+    // ranked boxes: (images, rank_cap) of whichever path runs; the mask of the fast path
+    if ((size_t)batch > ctx->det_cap || (size_t)rank_cap > ctx->det_rank_cap) {
         SSD_CHECK_HIP(hipStreamSynchronize(ctx->stream));
         void *old[] = {ctx->sboxes, ctx->sscores, ctx->sidx, ctx->keff, ctx->mask};
         for (void *p : old)
@@ -887,11 +1029,13 @@ int ensure_detect_scratch(ssdbox_ctx *ctx, int batch, long long nseg)
         ctx->sidx = nullptr;
         ctx->keff = nullptr;
         ctx->mask = nullptr;
+        const size_t cap = std::max((size_t)batch + (size_t)batch / 4, ctx->det_cap);
+        const size_t ranks = std::max((size_t)rank_cap, ctx->det_rank_cap);
         ctx->det_cap = 0;
-        const size_t cap = (size_t)batch + (size_t)batch / 4;
-        hipError_t e = hipMalloc((void **)&ctx->sboxes, cap * kLimit * sizeof(float4));
-        if (e == hipSuccess) e = hipMalloc((void **)&ctx->sscores, cap * kLimit * sizeof(float));
-        if (e == hipSuccess) e = hipMalloc((void **)&ctx->sidx, cap * kLimit * sizeof(int));
+        ctx->det_rank_cap = 0;
+        hipError_t e = hipMalloc((void **)&ctx->sboxes, cap * ranks * sizeof(float4));
+        if (e == hipSuccess) e = hipMalloc((void **)&ctx->sscores, cap * ranks * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void **)&ctx->sidx, cap * ranks * sizeof(int));
         if (e == hipSuccess) e = hipMalloc((void **)&ctx->keff, cap * sizeof(int));
         if (e == hipSuccess) e = hipMalloc((void **)&ctx->mask, cap * kLimit * kWords * sizeof(u64));
         if (e != hipSuccess) {
@@ -899,6 +1043,7 @@ int ensure_detect_scratch(ssdbox_ctx *ctx, int batch, long long nseg)
             return SSDBOX_ERR_NOMEM;
         }
         ctx->det_cap = cap;
+        ctx->det_rank_cap = ranks;
     }
     return SSDBOX_OK;
 }
@@ -918,7 +1063,8 @@ int run_detect(ssdbox_ctx *ctx, const ScoreLayout &sl, long long n, int batch, f
                float *d_dets, int32_t *d_keep, int32_t *d_count)
 {
     const int nseg = (int)((n + kSeg - 1) / kSeg);
-    int rc = ensure_detect_scratch(ctx, batch, nseg);
+    const bool big = limit > kLimit;
+    int rc = ensure_detect_scratch(ctx, batch, nseg, big ? kBigLimit : kLimit);
     if (rc != SSDBOX_OK) return rc;
     {
         dim3 grid((unsigned)((nseg + kSelBlock / 64 - 1) / (kSelBlock / 64)), batch);
@@ -977,16 +1123,18 @@ int run_detect(ssdbox_ctx *ctx, const ScoreLayout &sl, long long n, int batch, f
         a.sscores = ctx->sscores;
         a.sidx = ctx->sidx;
         a.keff = ctx->keff;
-        launch_stage(ctx, SSDBOX_STAGE_TOPK, topk_sort_kernel, dim3(batch), dim3(kTopkBlock), a);
+        if (big) launch_stage(ctx, SSDBOX_STAGE_TOPK, topk_sort_kernel<kBigRanks>, dim3(batch), dim3(kTopkBlock), a);
+        else launch_stage(ctx, SSDBOX_STAGE_TOPK, topk_sort_kernel<1>, dim3(batch), dim3(kTopkBlock), a);
     }
     SSD_CHECK_HIP(hipGetLastError());
-    {
+    if (big) {
+        launch_stage(ctx, SSDBOX_STAGE_NMS_SCAN, nms_greedy_big_kernel, dim3(batch), dim3(kTopkBlock), ctx->sboxes,
+                     ctx->sscores, ctx->sidx, ctx->keff, nms_thr, limit, d_img_wh, d_dets, d_keep, d_count);
+    } else {
         const int kw = (limit + 63) / 64;
         launch_stage(ctx, SSDBOX_STAGE_NMS_MASK, nms_mask_kernel, dim3(kw * (kw + 1) / 2, batch), dim3(64),
                      ctx->sboxes, ctx->keff, nms_thr, ctx->mask);
-    }
-    SSD_CHECK_HIP(hipGetLastError());
-    {
+        SSD_CHECK_HIP(hipGetLastError());
         launch_stage(ctx, SSDBOX_STAGE_NMS_SCAN, nms_scan_kernel, dim3(batch), dim3(kLimit), ctx->mask,
                      ctx->sboxes, ctx->sscores, ctx->sidx, ctx->keff, limit, d_img_wh, d_dets,
                      d_keep, d_count);
@@ -1009,8 +1157,8 @@ static int decode_nms_common(ssdbox_ctx *ctx, const ssdbox_geom *geom, const flo
     SSD_REQUIRE(d_y_pred && d_dets && d_keep_idx && d_count, "decode_nms: NULL buffer");
     SSD_REQUIRE(batch >= 1 && batch <= 65535, "decode_nms: batch %d outside [1, 65535]", batch);
     SSD_REQUIRE(limit >= 1, "decode_nms: limit %d < 1", limit);
-    if (limit > kLimit) {
-        set_error("decode_nms: limit %d above the supported %d", limit, kLimit);
+    if (limit > kBigLimit) {
+        set_error("decode_nms: limit %d above the supported %d", limit, kBigLimit);
         return SSDBOX_ERR_UNSUPPORTED;
     }
     // the reference loop never ends for thresholds >= 1 (a box's IoU with itself is <= thr)
@@ -1087,8 +1235,8 @@ extern "C" int ssdbox_compute_nms(ssdbox_ctx *ctx, const float *d_boxes, const f
     }
     SSD_REQUIRE(d_boxes && d_scores && d_keep, "compute_nms: NULL buffer");
     const int k = (int)((n < (int64_t)limit) ? n : (int64_t)limit);
-    if (k > kLimit) {
-        set_error("compute_nms: min(limit, n) = %d above the supported %d", k, kLimit);
+    if (k > kBigLimit) {
+        set_error("compute_nms: min(limit, n) = %d above the supported %d", k, kBigLimit);
         return SSDBOX_ERR_UNSUPPORTED;
     }
     BoxSource src;

@@ -108,6 +108,7 @@ struct ssdbox_ctx {
     int *keff;                     // (batch) effective K per image
     unsigned long long *mask;      // (batch, LIMIT, LIMIT/64) suppression bits
     size_t det_cap;                // images
+    size_t det_rank_cap;           // ranked boxes per image the buffers above hold
     int *selftest_out;
 
     // buffer surface (ssdbox_buf.hip): buffers handed out, freed buffers kept for reuse, and the

@@ -376,7 +376,37 @@ def test_compute_nms_conventions(fda):
     with pytest.raises(ValueError):
         nms(boxes, np.array([.9, .8, .7], F32), 1.0, 10)
     with pytest.raises(NotImplementedError):
-        nms(many, same, 0.45, 5000)
+        nms(many, same, 0.45, 5000)         # min(limit, n) above the library's 4096
+
+
+@pytest.mark.parametrize("n,limit", [(1025, 4096), (3000, 2000), (6000, 3000), (6000, 4096), (20000, 4096)])
+def test_compute_nms_more_than_1024_ranks(fda, n, limit):
+    """compute_nms takes any limit (utils/box_utils.py:184,202); above 1024 ranked boxes the
+    library runs its general path (sort in LDS, the reference's greedy loop): same kept lists as
+    the oracle, with clusters, exact score ties and degenerate boxes."""
+    nms = fda.box_utils.compute_nms
+    rng = np.random.default_rng(n + limit)
+    boxes = clustered_boxes(rng, n)
+    scores = rng.uniform(0, 1, n).astype(F32)
+    scores[rng.integers(0, n, n // 8)] = F32(0.5)                 # ties: the lower index ranks first
+    boxes[rng.integers(0, n, 20), 2] = boxes[rng.integers(0, n, 20), 0]
+    for thr in (0.45, 0.0, -1.0):
+        np.testing.assert_array_equal(nms(boxes, scores, thr, limit), C.compute_nms(boxes, scores, thr, limit))
+    same = np.full((n,), 0.25, F32)
+    np.testing.assert_array_equal(nms(boxes, same, 0.45, limit), C.compute_nms(boxes, same, 0.45, limit))
+
+
+def test_decode_nms_more_than_1024_ranks(fda):
+    rng = np.random.default_rng(31)
+    cfg = ssd_config(256)
+    boxes, _, counts = S.make_ground_truth(rng, 3, 256, gmax=24)
+    y = S.make_head_outputs(rng, cfg, boxes, counts, n_ties=300)
+    wh = rng.uniform(100, 2000, (3, 2)).astype(F32)
+    check_decode_nms(fda, cfg, y, 0.0, wh, limit=2500)
+    check_decode_nms(fda, cfg, y, 0.01, None, "array", limit=4096)
+    check_decode_nms(fda, cfg, y, 0.05, None, limit=1025)
+    # and the fast path again on the same context (the ranked-box buffers are laid out wider now)
+    check_decode_nms(fda, cfg, y, 0.05, wh, limit=1000)
 
 
 def test_compute_nms_mask_paths(fda):

@@ -182,3 +182,33 @@ def test_match_encode_widest_cells_and_tallest_tiles(fda, gmax):
         np.testing.assert_array_equal(bits(miou[b]), bits(c_iou))
         np.testing.assert_array_equal(bits(conf[b]), bits(c_conf))
         np.testing.assert_array_equal(bits(locs[b]), bits(c_locs))
+
+
+CROWDED_SEEDS = range(int(os.environ.get("SSDBOX_FUZZ_CROWDED_SEEDS", "4")))
+
+
+@pytest.mark.parametrize("seed", CROWDED_SEEDS)
+def test_fuzz_match_encode_crowded(fda, seed):
+    """Random geometries on larger images with full and overfull box lists: tall tiles, long
+    walks, more than one list of 256 boxes per image."""
+    rng = np.random.default_rng(9000 + seed)
+    cfg = random_config(rng)
+    cfg['img_height'], cfg['img_width'] = int(rng.integers(320, 700)), int(rng.integers(96, 400))
+    cfg['image_size'] = (cfg['img_height'], cfg['img_width'])
+    anchors_np = O.generate_anchors(cfg)
+    grid = fda.anchor_utils.generate_anchors(cfg)
+    gmax = int(rng.choice([200, 256, 257, 300, 600]))
+    boxes, labels, counts = random_ground_truth(rng, 3, gmax)
+    counts[0] = gmax
+    boxes0, labels0, _ = random_ground_truth(rng, 1, gmax)
+    boxes[0, :], labels[0, :] = boxes0[0], labels0[0]
+    max_size = float(max(cfg['image_size']))
+    conf, locs, midx, miou = fda.match_encode_batch(grid, boxes, counts, labels, max_size, 0.5, return_match=True)
+    for b in range(3):
+        g = counts[b]
+        c_conf, c_locs, c_idx, c_iou, _ = C.compute_target(anchors_np, boxes[b, :g], labels[b, :g], max_size, 0.5,
+                                                           details=True)
+        np.testing.assert_array_equal(np.asarray(midx[b]), c_idx)
+        np.testing.assert_array_equal(bits(miou[b]), bits(c_iou))
+        np.testing.assert_array_equal(bits(conf[b]), bits(c_conf))
+        np.testing.assert_array_equal(bits(locs[b]), bits(c_locs))

@@ -335,8 +335,9 @@ SSD_DEV void geom_tile(const MatchArgs &p, MatchShared &sm, const MatchLayer &L)
     const unsigned k = n_box == 1u ? 0u : c - __umulhi(c, L.nbox_magic) * n_box;
     const float4 *cols = p.col_tab + L.col_off;               // padded by a tile per layer
     const float4 col = ld_off<float4>(cols, c * 16u);
-    // the layer's box shapes are the (w, h) of its first n_box anchor columns
-    const float4 shape_mine = ld_off<float4>(cols, min(t, n_box - 1u) * 16u);
+    // the layer's box shapes are the (w, h) of its first n_box anchor columns: lane k of every
+    // wave holds shape k
+    const float4 shape_l = ld_off<float4>(cols, min(lane, n_box - 1u) * 16u);
     float cy_mine = 0.0f;
     if ((int)t < tile_rows) cy_mine = p.cy_tab[L.cy_off + min(t_r0 + (int)t, L.fm_h - 1)];
     const float acx = col.x, aw = col.y, ah = col.z;
@@ -353,7 +354,7 @@ SSD_DEV void geom_tile(const MatchArgs &p, MatchShared &sm, const MatchLayer &L)
     const float ahw = aw / 2.0f, ahh = ah / 2.0f;
     const float ax0 = acx - ahw, ax1 = acx + ahw;            // transform_center_to_corner, :177-179
     const float a_w = clip0(ax1 - ax0, p.max_size);
-    if (t < n_box) sm.shape_wh[t] = make_float2(shape_mine.y, shape_mine.z);
+    if (t < n_box) sm.shape_wh[t] = make_float2(shape_l.y, shape_l.z);
     if (!MULTI) {
         // What only the final encode of a row needs waits in LDS (read back by the same thread),
         // not in registers that would stay occupied during the walk over the boxes: the
@@ -370,6 +371,24 @@ SSD_DEV void geom_tile(const MatchArgs &p, MatchShared &sm, const MatchLayer &L)
     int sel[R];
     bool touched = false;
 
+    // Tables that do not depend on the box list, written before its barriers: row centres, the
+    // y offsets against box 0 per (row, shape), box 0's log-size offsets per shape.  A tile that
+    // lists no box goes from the list's first barrier straight to its stores.
+    if ((int)t < tile_rows) {
+        s_cy[t] = cy_mine;
+        if (!MULTI) {
+            const float dy = (b0.y + b0.w) / 2.0f - cy_mine;
+#pragma unroll 1
+            for (unsigned kk = 0; kk < n_box; ++kk) {
+                const float sh = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(shape_l.z), (int)kk));
+                s_ty0[t * n_box + kk] = dy / (sh * 0.1f);
+            }
+        }
+    }
+    if (!MULTI && t < n_box)
+        s_lwh[(unsigned)kListCap * n_box + t] = make_float2(ssd_logf((b0.z - b0.x) / shape_l.y) / 0.2f,
+                                                            ssd_logf((b0.w - b0.y) / shape_l.z) / 0.2f);
+
     int par = 0;
     for (int g0 = 0; g0 < G; g0 += kListCap, par ^= 1) {
         const int g = g0 + (int)t;
@@ -381,31 +400,20 @@ SSD_DEV void geom_tile(const MatchArgs &p, MatchShared &sm, const MatchLayer &L)
         }
         const int n_list = build_list(sm, par, t, lane, wave, g, g < G, b, lab, ex0, ey0, ex1, ey1, p.max_size);
 
-        if (g0 == 0) {
-            if ((int)t < tile_rows) {
-                s_cy[t] = cy_mine;
-                if (!MULTI) {
-                    const float dy = (b0.y + b0.w) / 2.0f - cy_mine;
-#pragma unroll 1
-                    for (unsigned kk = 0; kk < n_box; ++kk) s_ty0[t * n_box + kk] = dy / (sm.shape_wh[kk].y * 0.1f);
-                }
-            }
-        }
-        if (!MULTI) {
-            // log-size offsets of the listed boxes and of box 0, one (box, shape) item per thread
-            const unsigned n_items = (unsigned)(n_list + 1) * n_box;
+        if (!MULTI && n_list != 0) {
+            // log-size offsets of the listed boxes, one (box, shape) item per thread
+            const unsigned n_items = (unsigned)n_list * n_box;
 #pragma unroll 1
             for (unsigned item = t; item < n_items; item += kBlock) {
                 const unsigned q = n_box == 1u ? item : __umulhi(item, L.nbox_magic);
                 const unsigned kk = item - q * n_box;
                 const float2 sh = sm.shape_wh[kk];
-                const float4 bx = (int)q < n_list ? sm.box[q] : b0;
-                const unsigned slot = (int)q < n_list ? q : (unsigned)kListCap;
-                s_lwh[slot * n_box + kk] =
+                const float4 bx = sm.box[q];
+                s_lwh[q * n_box + kk] =
                     make_float2(ssd_logf((bx.z - bx.x) / sh.x) / 0.2f, ssd_logf((bx.w - bx.y) / sh.y) / 0.2f);
             }
+            __syncthreads();
         }
-        if (!MULTI || g0 == 0) __syncthreads();
 
 #pragma unroll 1
         for (int gi = wave; gi < n_groups_here; gi += kBlock / 64) {

@@ -24,7 +24,7 @@ def run(name):
         r.append(t / args.steps * 1e6)
     st = bench.stage_times(wl, 30)
     print("%-28s boxes %5d  half %s us per batch   kernel alone: match %.2f force %.2f us"
-          % (name, int(wl.d_counts.sum().item()), [round(x, 2) for x in r], st["match"], st["force"]))
+          % (name, int(wl.d_counts.sum().item()), [round(x, 2) for x in r], st["match"], st.get("force", 0.0)))
 
 
 run("bench batch")

@@ -6,6 +6,9 @@
 //   B  tile 64 columns x 80 rows; a wave stores one row x 64 columns per instruction
 //   C  tile 128 columns x 40 rows; a wave stores one row x 64 columns, two waves side by side
 //   L  a wave stores 64 consecutive anchors per instruction, a workgroup a contiguous range
+//   P  pattern A behind a prologue like the match kernel's: one round trip to memory, two
+//      barriers and about a microsecond of arithmetic before the first store
+//   Q  pattern A at the match kernel's occupancy (five waves per SIMD) without a prologue
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <chrono>
@@ -26,7 +29,21 @@ __global__ __launch_bounds__(256) void store_kernel(float *conf, vf4 *locs, floa
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long img = (long long)blockIdx.y * kPerImage;
-    if (MODE == 0) {                // A: blockIdx.x = column tile of 32
+    __shared__ float s_x[256];
+    __shared__ char s_pad[MODE == 5 ? 30000 : 1];      // five workgroups per CU
+    if (MODE == 5 && v == 12345.f) s_pad[threadIdx.x] = 1;
+    if (MODE == 4) {
+        // what was stored last time comes back (a dependent round trip), then barriers and arithmetic
+        float x = conf[img + (long long)blockIdx.x * 32 + threadIdx.x];
+        s_x[threadIdx.x] = x;
+        __syncthreads();
+        float y = s_x[255 - threadIdx.x];
+        for (int i = 0; i < 150; ++i) y = y / (x + 1.5f) + 0.25f;      // ~1 us of dependent divisions
+        s_x[threadIdx.x] = y;
+        __syncthreads();
+        v += s_x[(threadIdx.x + 1) & 255] * 1e-30f;
+    }
+    if (MODE == 0 || MODE == 4 || MODE == 5) {                // A: blockIdx.x = column tile of 32
         const int c = blockIdx.x * 32 + (lane & 31), half = lane >> 5;
         for (int g = wave; g < kRows / 8; g += 4)
 #pragma unroll
@@ -94,6 +111,8 @@ int main()
     run<1>("B 1 row x 64 columns ", s, conf, locs);
     run<2>("C 128-column tiles   ", s, conf, locs);
     run<3>("L contiguous         ", s, conf, locs);
+    run<4>("P A behind a prologue", s, conf, locs);
+    run<5>("Q A, 5 workgroups/CU ", s, conf, locs);
     run<0>("A again              ", s, conf, locs);
     return 0;
 }

@@ -61,6 +61,33 @@ SSD_DEV float softmax_face(float l0, float l1)
 // per CU, three items per wave) was measured and is slower, alone (15.2 against 13.3 us) and with
 // four batches in flight (decode+NMS 1.38e6 against 1.48e6 images/s).
 constexpr int kSelWgsPerCu = 64;
+constexpr int kHistSegs = 8;               // segments per workgroup of the histogram kernels
+SSD_DEV int prune_bin(u64 key, int has_range, float lo, float scale);
+
+// One item (256 anchors = 384 float4 held by the wave): the keys of the anchors that pass, packed
+// into `out`; returns their number.  on_key(key) runs on every lane that holds a passing anchor.
+template <bool LOGITS, typename F>
+SSD_DEV int compact_rows6(const float4 (&v)[6], unsigned f0, unsigned nf, float thr, u64 *out, u64 lt, F on_key)
+{
+    int off = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const unsigned f = f0 + 64u * k;
+        const unsigned q = __umulhi(f, 0xAAAAAAABu) >> 1;      // f / 3
+        const unsigned r = f - 3u * q;
+        const float s1 = (r == 0u) ? v[k].y : v[k].w;
+        const float score = LOGITS ? softmax_face((r == 0u) ? v[k].x : v[k].z, s1) : s1;
+        const bool pass = (f < nf) && (r != 2u) && (score > thr);   // strict >, NaN fails
+        const u64 bal = __ballot(pass);
+        if (pass) {
+            const u64 key = rank_key(score, 2u * q + r);
+            out[off + __popcll(bal & lt)] = key;
+            on_key(key);
+        }
+        off += __popcll(bal);
+    }
+    return off;
+}
 
 template <bool LOGITS>
 __global__ __launch_bounds__(kSelBlock) void select_rows6_kernel(const float4 *__restrict__ y, int n,
@@ -96,25 +123,66 @@ __global__ __launch_bounds__(kSelBlock) void select_rows6_kernel(const float4 *_
         const int img = udiv_magic(item, nseg, nseg_magic);
         const int seg = item - img * nseg;
         const unsigned f0 = (unsigned)seg * 384u + (unsigned)lane;
-        u64 *out = cand + (long long)item * kSeg;
-        int off = 0;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            const unsigned f = f0 + 64u * k;
-            const unsigned q = __umulhi(f, 0xAAAAAAABu) >> 1;      // f / 3
-            const unsigned r = f - 3u * q;
-            const float s1 = (r == 0u) ? v[k].y : v[k].w;
-            const float score = LOGITS ? softmax_face((r == 0u) ? v[k].x : v[k].z, s1) : s1;
-            const bool pass = (f < nf) && (r != 2u) && (score > thr);   // strict >, NaN fails
-            const u64 bal = __ballot(pass);
-            if (pass) out[off + __popcll(bal & lt)] = rank_key(score, 2u * q + r);
-            off += __popcll(bal);
-        }
+        const int off = compact_rows6<LOGITS>(v, f0, nf, thr, cand + (long long)item * kSeg, lt, [](u64) {});
         if (lane == 0) seg_count[item] = off;
         if (next >= n_items) break;
         item = next;
 #pragma unroll
         for (int k = 0; k < 6; ++k) v[k] = vn[k];
+    }
+}
+
+// The same with the per-image histogram of the candidates' bins (what cand_prune_kernel cuts
+// by), for calls where most anchors are candidates: a workgroup takes kHistSegs consecutive
+// segments of one image, counts in LDS and adds its non-empty bins to the image's histogram,
+// which saves the pass of cand_hist_kernel over the keys and its launch.
+template <bool LOGITS>
+__global__ __launch_bounds__(kSelBlock) void select_rows6_hist_kernel(const float4 *__restrict__ y, int n, float thr,
+                                                                      u64 *__restrict__ cand,
+                                                                      int *__restrict__ seg_count, int nseg,
+                                                                      int has_range, float lo, float scale,
+                                                                      unsigned int *__restrict__ hist)
+{
+    __shared__ unsigned int s_hist[kBins];
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int img = blockIdx.y;
+    const unsigned nf = (unsigned)n / 2u * 3u;
+    const u64 lt = (1ull << lane) - 1ull;
+    const float4 *src = y + (long long)img * nf;
+    const int s_end = min(((int)blockIdx.x + 1) * kHistSegs, nseg);
+    int seg = blockIdx.x * kHistSegs + wave;
+
+    auto fetch = [&](int sg, float4 (&v)[6]) {
+        const unsigned f0 = (unsigned)sg * 384u + (unsigned)lane;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const unsigned f = f0 + 64u * k;
+            v[k] = (f < nf) ? src[f] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    float4 v[6];
+    if (seg < s_end) fetch(seg, v);
+    for (int b = t; b < kBins; b += kSelBlock) s_hist[b] = 0u;
+    __syncthreads();
+    while (seg < s_end) {
+        const int next = seg + kSelBlock / 64;
+        float4 vn[6];
+        if (next < s_end) fetch(next, vn);
+        const unsigned f0 = (unsigned)seg * 384u + (unsigned)lane;
+        const long long item = (long long)img * nseg + seg;
+        const int off = compact_rows6<LOGITS>(v, f0, nf, thr, cand + item * kSeg, lt, [&](u64 key) {
+            atomicAdd(&s_hist[prune_bin(key, has_range, lo, scale)], 1u);
+        });
+        if (lane == 0) seg_count[item] = off;
+        seg = next;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) v[k] = vn[k];
+    }
+    __syncthreads();
+    for (int b = t; b < kBins; b += kSelBlock) {
+        const unsigned int c = s_hist[b];
+        if (c != 0u) atomicAdd(&hist[(long long)img * kBins + b], c);
     }
 }
 
@@ -160,8 +228,6 @@ __global__ __launch_bounds__(kSelBlock) void select_strided_kernel(
 //                        `limit`; every wave rewrites its own segment with the keys at or above
 //                        that bin (all of the `limit` largest keys are among them)
 // The top-k kernel then runs unchanged on what is left.
-constexpr int kHistSegs = 16;              // segments per workgroup of cand_hist_kernel
-
 // Monotone non-decreasing map from rank key to one of kBins bins: linear in the score when the
 // scores are known to lie in [lo, lo + 2047 / scale], the leading key bits otherwise.
 SSD_DEV int prune_bin(u64 key, int has_range, float lo, float scale)
@@ -289,6 +355,7 @@ struct TopkArgs {
     float *sscores;
     int *sidx;
     int *keff;
+    unsigned int *hist_clear;     // not NULL: the image's pruning histogram, zeroed for the next call
 };
 
 // Monotone non-decreasing map from rank key to one of kBins linear score bins.
@@ -453,6 +520,10 @@ __global__ __launch_bounds__(kTopkBlock) void topk_sort_kernel(const TopkArgs p)
     }
     const int K = min(n, p.limit);
     if (t == 0) p.keff[img] = K;
+    if (p.hist_clear != nullptr) {
+        static_assert(kBins == 2 * kTopkBlock, "two bins per thread");
+        reinterpret_cast<uint2 *>(p.hist_clear + (long long)img * kBins)[t] = make_uint2(0u, 0u);
+    }
     if (n == 0) return;
     SSD_STAMP();
 
@@ -1016,7 +1087,7 @@ int ensure_detect_scratch(ssdbox_ctx *ctx, int batch, long long nseg, int rank_c
                        sizeof(int), false, ctx->stream);
     if (rc != SSDBOX_OK) return rc;
     rc = ensure_buffer((void **)&ctx->cand_hist, &ctx->hist_cap, (size_t)batch * kBins, sizeof(unsigned int),
-                       false, ctx->stream);
+                       true, ctx->stream);
     if (rc != SSDBOX_OK) return rc;
     // ranked boxes: (images, rank_cap) of whichever path runs; the mask of the fast path
     if ((size_t)batch > ctx->det_cap || (size_t)rank_cap > ctx->det_rank_cap) {
@@ -1066,6 +1137,22 @@ int run_detect(ssdbox_ctx *ctx, const ScoreLayout &sl, long long n, int batch, f
     const bool big = limit > kLimit;
     int rc = ensure_detect_scratch(ctx, batch, nseg, big ? kBigLimit : kLimit);
     if (rc != SSDBOX_OK) return rc;
+    // head scores are softmax outputs: spread the linear bins over (threshold, 1]
+    const int has_range = (sl.use_thr && sl.thr >= 0.0f && sl.thr < 1.0f) ? 1 : 0;
+    const float range_lo = has_range ? sl.thr : 0.0f;
+    const float range_scale = has_range ? (float)(kBins - 1) / (1.0f - sl.thr) : 0.0f;
+    // Most anchors are candidates when there is no threshold or one below the usual detection
+    // thresholds: prune before the one-workgroup-per-image kernel (a guess about speed only,
+    // both ways give the same result).  The per-image histogram the pruning cuts by is all zero
+    // between calls: the top-k kernel clears what this call counted.
+    const bool dense = n > kCap && (!sl.use_thr || sl.thr < 0.02f);
+    if (dense) {
+        if (ctx->hist_dirty)
+            SSD_CHECK_HIP(hipMemsetAsync(ctx->cand_hist, 0, ctx->hist_cap * sizeof(unsigned int), ctx->stream));
+        ctx->hist_dirty = true;        // until every launch of this call is enqueued
+    }
+    const dim3 hist_grid((nseg + kHistSegs - 1) / kHistSegs, batch);
+    bool counted = false;              // the select kernel filled the histogram itself
     {
         dim3 grid((unsigned)((nseg + kSelBlock / 64 - 1) / (kSelBlock / 64)), batch);
         const long long n_items = (long long)nseg * batch;
@@ -1074,14 +1161,23 @@ int run_detect(ssdbox_ctx *ctx, const ScoreLayout &sl, long long n, int batch, f
         const unsigned pgrid = (unsigned)std::min<long long>((n_items + kSelBlock / 64 - 1) / (kSelBlock / 64),
                                                              (long long)ctx->num_cus * kSelWgsPerCu);
         const unsigned nseg_magic = nseg > 1 ? (unsigned)(((1ull << 32) + (unsigned)nseg - 1) / (unsigned)nseg) : 0u;
-        if (rows6 && sl.logits) {
-            launch_stage(ctx, SSDBOX_STAGE_SELECT, select_rows6_kernel<true>, dim3(pgrid), dim3(kSelBlock),
-                         reinterpret_cast<const float4 *>(sl.scores), (int)n, sl.thr, ctx->cand,
-                         ctx->cand_count, nseg, (int)n_items, nseg_magic);
+        const float4 *rows = reinterpret_cast<const float4 *>(sl.scores);
+        if (rows6 && dense) {
+            counted = true;
+            if (sl.logits)
+                launch_stage(ctx, SSDBOX_STAGE_SELECT, select_rows6_hist_kernel<true>, hist_grid, dim3(kSelBlock), rows,
+                             (int)n, sl.thr, ctx->cand, ctx->cand_count, nseg, has_range, range_lo, range_scale,
+                             ctx->cand_hist);
+            else
+                launch_stage(ctx, SSDBOX_STAGE_SELECT, select_rows6_hist_kernel<false>, hist_grid, dim3(kSelBlock), rows,
+                             (int)n, sl.thr, ctx->cand, ctx->cand_count, nseg, has_range, range_lo, range_scale,
+                             ctx->cand_hist);
+        } else if (rows6 && sl.logits) {
+            launch_stage(ctx, SSDBOX_STAGE_SELECT, select_rows6_kernel<true>, dim3(pgrid), dim3(kSelBlock), rows,
+                         (int)n, sl.thr, ctx->cand, ctx->cand_count, nseg, (int)n_items, nseg_magic);
         } else if (rows6) {
-            launch_stage(ctx, SSDBOX_STAGE_SELECT, select_rows6_kernel<false>, dim3(pgrid), dim3(kSelBlock),
-                         reinterpret_cast<const float4 *>(sl.scores), (int)n, sl.thr, ctx->cand,
-                         ctx->cand_count, nseg, (int)n_items, nseg_magic);
+            launch_stage(ctx, SSDBOX_STAGE_SELECT, select_rows6_kernel<false>, dim3(pgrid), dim3(kSelBlock), rows,
+                         (int)n, sl.thr, ctx->cand, ctx->cand_count, nseg, (int)n_items, nseg_magic);
         } else {
             launch_stage(ctx, SSDBOX_STAGE_SELECT, select_strided_kernel, grid, dim3(kSelBlock),
                          sl.scores, sl.img_stride, sl.elem_stride, sl.elem_off, (int)n, sl.thr,
@@ -1089,18 +1185,10 @@ int run_detect(ssdbox_ctx *ctx, const ScoreLayout &sl, long long n, int batch, f
         }
     }
     SSD_CHECK_HIP(hipGetLastError());
-    // head scores are softmax outputs: spread the linear bins over (threshold, 1]
-    const int has_range = (sl.use_thr && sl.thr >= 0.0f && sl.thr < 1.0f) ? 1 : 0;
-    const float range_lo = has_range ? sl.thr : 0.0f;
-    const float range_scale = has_range ? (float)(kBins - 1) / (1.0f - sl.thr) : 0.0f;
-    // Most anchors are candidates when there is no threshold or one below the usual detection
-    // thresholds: prune before the one-workgroup-per-image kernel (a guess about speed only,
-    // both ways give the same result).
-    if (n > kCap && (!sl.use_thr || sl.thr < 0.02f)) {
-        SSD_CHECK_HIP(hipMemsetAsync(ctx->cand_hist, 0, (size_t)batch * kBins * sizeof(unsigned int), ctx->stream));
-        launch_stage(ctx, SSDBOX_STAGE_PRUNE, cand_hist_kernel, dim3((nseg + kHistSegs - 1) / kHistSegs, batch),
-                     dim3(kSelBlock), ctx->cand, ctx->cand_count, nseg, has_range, range_lo, range_scale,
-                     ctx->cand_hist);
+    if (dense) {
+        if (!counted)
+            launch_stage(ctx, SSDBOX_STAGE_PRUNE, cand_hist_kernel, hist_grid, dim3(kSelBlock), ctx->cand,
+                         ctx->cand_count, nseg, has_range, range_lo, range_scale, ctx->cand_hist);
         launch_stage(ctx, SSDBOX_STAGE_PRUNE, cand_prune_kernel,
                      dim3((nseg + kSelBlock / 64 - 1) / (kSelBlock / 64), batch), dim3(kSelBlock), ctx->cand,
                      ctx->cand_count, nseg, limit, has_range, range_lo, range_scale, ctx->cand_hist);
@@ -1123,6 +1211,7 @@ int run_detect(ssdbox_ctx *ctx, const ScoreLayout &sl, long long n, int batch, f
         a.sscores = ctx->sscores;
         a.sidx = ctx->sidx;
         a.keff = ctx->keff;
+        a.hist_clear = dense ? ctx->cand_hist : nullptr;
         if (big) launch_stage(ctx, SSDBOX_STAGE_TOPK, topk_sort_kernel<kBigRanks>, dim3(batch), dim3(kTopkBlock), a);
         else launch_stage(ctx, SSDBOX_STAGE_TOPK, topk_sort_kernel<1>, dim3(batch), dim3(kTopkBlock), a);
     }
@@ -1140,6 +1229,7 @@ int run_detect(ssdbox_ctx *ctx, const ScoreLayout &sl, long long n, int batch, f
                      d_keep, d_count);
     }
     SSD_CHECK_HIP(hipGetLastError());
+    if (dense) ctx->hist_dirty = false;
     return SSDBOX_OK;
 }
 

@@ -102,6 +102,7 @@ struct ssdbox_ctx {
     size_t count_cap;
     unsigned int *cand_hist;       // (batch, 2048) score histogram for the pruning pass
     size_t hist_cap;
+    bool hist_dirty;               // a call was enqueued only in part: the histogram is not all zero
     float4 *sboxes;                // (batch, LIMIT) decoded boxes in rank order
     float *sscores;
     int *sidx;

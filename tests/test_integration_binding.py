@@ -1,5 +1,6 @@
-"""The stand-alone ctypes binding INTEGRATION.md shows (no face_detection_amd import: only the
-shared library and the header's signatures), run against the numpy oracle."""
+"""A stand-alone ctypes binding of the kind a maintainer of the reference would write (no
+face_detection_amd import: only the shared library and the header's signatures), run against
+the numpy oracle."""
 import ctypes
 import os
 

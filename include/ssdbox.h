@@ -47,11 +47,11 @@ enum {
     SSDBOX_STAGE_SELECT = 2,     /* score threshold + candidate compaction over y_pred       */
     SSDBOX_STAGE_TOPK = 3,       /* per-image top-k select, sort, decode of survivors        */
     SSDBOX_STAGE_NMS_MASK = 4,   /* K x K suppression bit matrix                             */
-    SSDBOX_STAGE_NMS_SCAN = 5,   /* greedy scan + detection assembly                         */
+    SSDBOX_STAGE_NMS_SCAN = 5,   /* greedy scan + detection assembly (limit > 1024: whole NMS) */
     SSDBOX_STAGE_ELEMENTWISE = 6,
-    SSDBOX_STAGE_SHAPES = 7,     /* per (GT box, anchor shape) log-size table before matching */
+    SSDBOX_STAGE_SHAPES = 7,     /* unused (the per-box tables are built inside the match launch) */
     SSDBOX_STAGE_LOSS = 8,       /* SSD loss with hard-negative mining (all its launches)    */
-    SSDBOX_STAGE_PRUNE = 9,      /* candidate histogram + pruning when most anchors pass      */
+    SSDBOX_STAGE_PRUNE = 9,      /* candidate pruning (+ histogram) when most anchors pass     */
     SSDBOX_NUM_STAGES = 10
 };
 

@@ -33,12 +33,18 @@ for slot in wl.slots:
         wl.detect(slot)
     graphs.append(g)
 torch.cuda.synchronize()
+def replay(i):
+    # (replay() launches on torch's current stream: each graph goes to its slot's stream)
+    with torch.cuda.stream(wl.slots[i % len(graphs)]["stream"]):
+        graphs[i % len(graphs)].replay()
+
+
 for i in range(40):
-    graphs[i % len(graphs)].replay()
+    replay(i)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for i in range(steps):
-    graphs[i % len(graphs)].replay()
+    replay(i)
 t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()

@@ -17,8 +17,13 @@ from face_detection_amd.utils import anchor_utils, box_utils        # noqa: E402
 
 
 def timeit(fn, reps=30):
-    for _ in range(40):                 # first-use costs (allocations, code loading) stay outside
+    # first-use costs (allocations, code loading) stay outside, and so does the slow start of a
+    # process that has just imported torch (the first few hundred milliseconds of calls run 5x slower)
+    t_warm = time.perf_counter()
+    n_warm = 0
+    while n_warm < 40 or time.perf_counter() - t_warm < 0.5:
         fn()
+        n_warm += 1
     t0 = time.perf_counter()
     for _ in range(reps):
         fn()

@@ -6,7 +6,9 @@
 // inference.py:38-60).
 #include <string.h>
 
+#include <mutex>
 #include <new>
+#include <vector>
 
 #include "ssdbox_internal.h"
 
@@ -41,6 +43,23 @@ struct DLManagedTensor {
     void (*deleter)(DLManagedTensor *self);
 };
 constexpr int kDLCPU = 1, kDLCUDAHost = 3, kDLROCM = 10, kDLROCMHost = 11;
+
+// Pinned host blocks handed out by ssdbox_host_alloc: a copy to one of them needs no staging.
+struct PinnedBlock {
+    char *base;
+    size_t bytes;
+};
+std::mutex g_pinned_mu;
+std::vector<PinnedBlock> g_pinned;
+
+bool is_library_pinned(const void *p, size_t bytes)
+{
+    const char *q = static_cast<const char *>(p);
+    std::lock_guard<std::mutex> lock(g_pinned_mu);
+    for (const PinnedBlock &b : g_pinned)
+        if (q >= b.base && q + bytes <= b.base + b.bytes) return true;
+    return false;
+}
 
 int ensure_staging(ssdbox_ctx *ctx)
 {
@@ -149,6 +168,11 @@ int copy_h2d_impl(ssdbox_ctx *ctx, void *d_dst, const void *h_src, size_t bytes)
 
 int copy_d2h_impl(ssdbox_ctx *ctx, void *h_dst, const void *d_src, size_t bytes)
 {
+    if (is_library_pinned(h_dst, bytes)) {         // the DMA writes the destination itself
+        SSD_CHECK_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        SSD_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        return SSDBOX_OK;
+    }
     int rc = ensure_staging(ctx);
     if (rc != SSDBOX_OK) return rc;
     const char *src = static_cast<const char *>(d_src);
@@ -261,6 +285,48 @@ extern "C" int ssdbox_buf_free(ssdbox_ctx *ctx, void *d_ptr)
     SSD_CHECK_HIP(hipFree(d_ptr));
     return SSDBOX_OK;
     SSD_NOTHROW_END
+}
+
+extern "C" int ssdbox_host_alloc(size_t bytes, void **h_out)
+{
+    SSD_REQUIRE(h_out != nullptr && bytes > 0, "ssdbox_host_alloc: NULL or empty");
+    *h_out = nullptr;
+    SSD_NOTHROW_BEGIN
+    {
+        std::lock_guard<std::mutex> lock(g_pinned_mu);
+        g_pinned.reserve(g_pinned.size() + 1);
+    }
+    void *p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocPortable);
+    if (e != hipSuccess) {
+        set_error("hipHostMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+        return SSDBOX_ERR_NOMEM;
+    }
+    std::lock_guard<std::mutex> lock(g_pinned_mu);
+    g_pinned.push_back({static_cast<char *>(p), bytes});
+    *h_out = p;
+    return SSDBOX_OK;
+    SSD_NOTHROW_END
+}
+
+extern "C" int ssdbox_host_free(void *h_ptr)
+{
+    if (h_ptr == nullptr) return SSDBOX_OK;
+    bool found = false;
+    {
+        std::lock_guard<std::mutex> lock(g_pinned_mu);
+        for (size_t i = 0; i < g_pinned.size(); ++i) {
+            if (g_pinned[i].base == h_ptr) {
+                g_pinned[i] = g_pinned.back();
+                g_pinned.pop_back();
+                found = true;
+                break;
+            }
+        }
+    }
+    SSD_REQUIRE(found, "ssdbox_host_free: %p did not come from ssdbox_host_alloc", h_ptr);
+    SSD_CHECK_HIP(hipHostFree(h_ptr));
+    return SSDBOX_OK;
 }
 
 extern "C" int ssdbox_copy_h2d(ssdbox_ctx *ctx, void *d_dst, const void *h_src, size_t bytes)

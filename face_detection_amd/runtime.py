@@ -175,6 +175,75 @@ def _capsule_destructor(capsule_addr):
         pass
 
 
+# ------------------------------------------------------------- pinned result arrays
+class _PinnedBlock:
+    """A pinned host block that numpy views as bytes; goes back to the pool when the last array
+    over it is gone."""
+
+    def __init__(self, pool, ptr, nbytes):
+        self._pool, self._ptr, self._nbytes = pool, ptr, nbytes
+        self.__array_interface__ = {"data": (ptr, False), "shape": (nbytes,), "typestr": "|u1", "version": 3}
+
+    def __del__(self):
+        try:
+            self._pool.release(self._ptr, self._nbytes)
+        except Exception:
+            pass
+
+
+class _PinnedPool:
+    """Result arrays of the numpy path live in pinned host memory, so that the copy from the
+    device writes them directly (ssdbox_copy_d2h needs no staging for them).  Blocks are pooled
+    by size; large, tiny or too many outstanding results fall back to ordinary numpy memory."""
+    GRANULE = 64 << 10
+    MIN_BYTES, MAX_BYTES = 64 << 10, 64 << 20
+    MAX_OUTSTANDING = 1 << 30          # pinned bytes in arrays the caller still holds
+    MAX_CACHED = 256 << 20             # pinned bytes kept for reuse
+
+    def __init__(self):
+        self._lock = threading.Lock()
+        self._free = {}                # size -> [ptr]
+        self._cached = 0
+        self._outstanding = 0
+
+    def empty(self, shape, dtype):
+        dtype = np.dtype(dtype)
+        nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+        if not self.MIN_BYTES <= nbytes <= self.MAX_BYTES:
+            return None
+        size = -(-nbytes // self.GRANULE) * self.GRANULE
+        ptr = None
+        with self._lock:
+            if self._outstanding + size > self.MAX_OUTSTANDING:
+                return None
+            blocks = self._free.get(size)
+            if blocks:
+                ptr = blocks.pop()
+                self._cached -= size
+            self._outstanding += size
+        if ptr is None:
+            out = ctypes.c_void_p()
+            if _lib.load().ssdbox_host_alloc(size, ctypes.byref(out)) != 0 or not out.value:
+                with self._lock:
+                    self._outstanding -= size
+                return None
+            ptr = out.value
+        raw = np.asarray(_PinnedBlock(self, ptr, size))
+        return raw[:nbytes].view(dtype).reshape(shape)
+
+    def release(self, ptr, size):
+        with self._lock:
+            self._outstanding -= size
+            if self._cached + size <= self.MAX_CACHED:
+                self._free.setdefault(size, []).append(ptr)
+                self._cached += size
+                return
+        _lib.load().ssdbox_host_free(ctypes.c_void_p(ptr))
+
+
+_pinned_pool = _PinnedPool()
+
+
 class DevArray:
     """A dense row-major array in device memory that the library allocated (or borrowed through
     DLPack), with the few tensor operations the host layer needs.  Views (indexing the first
@@ -269,7 +338,9 @@ class DevArray:
 
     def numpy(self):
         """A host copy; returns when the data has arrived (and the work before it has finished)."""
-        out = np.empty(self.shape, self.dtype)
+        out = _pinned_pool.empty(self.shape, self.dtype)
+        if out is None:
+            out = np.empty(self.shape, self.dtype)
         if out.nbytes:
             _lib.check(self.ctx.lib.ssdbox_copy_d2h(self.ctx.handle, out.ctypes.data_as(ctypes.c_void_p),
                                                     ctypes.c_void_p(self._ptr), out.nbytes))

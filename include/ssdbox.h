@@ -84,9 +84,14 @@ int ssdbox_ctx_collect_timing(ssdbox_ctx *ctx, float *ms, int32_t *launches);
  * ssdbox_copy_h2d: host memory (pageable is fine) -> device through the context's pinned staging
  *   ring, enqueued on the context's stream; returns once h_src may be reused.
  * ssdbox_copy_d2h: device -> host the same way; returns when h_dst holds the data (and with it
- *   everything enqueued on the stream before has finished).
- * ssdbox_copy_d2d: device -> device on the context's stream. */
+ *   everything enqueued on the stream before has finished).  A destination inside a block from
+ *   ssdbox_host_alloc is written by the DMA directly, without the staging copy.
+ * ssdbox_copy_d2d: device -> device on the context's stream.
+ * ssdbox_host_alloc / _free: pinned host memory any GPU of the process can copy to (for result
+ *   arrays a binding hands to its caller; the Python layer keeps a pool of them). */
 int ssdbox_device_count(void);
+int ssdbox_host_alloc(size_t bytes, void **h_out);
+int ssdbox_host_free(void *h_ptr);
 int ssdbox_buf_alloc(ssdbox_ctx *ctx, size_t bytes, void **d_out);
 int ssdbox_buf_free(ssdbox_ctx *ctx, void *d_ptr);
 int ssdbox_copy_h2d(ssdbox_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);

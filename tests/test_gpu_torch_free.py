@@ -108,6 +108,45 @@ def test_buffers_and_staged_copies():
     assert rc != 0 and b"not allocated" in ctx.lib.ssdbox_last_error()
 
 
+def test_result_arrays_in_pinned_memory():
+    """Results of the numpy path come back in pinned blocks from the library's pool (the copy from
+    the device writes them directly): they are ordinary writable arrays, stay valid while held,
+    and a block is reused only after every array over it is gone."""
+    import ctypes
+    import gc
+    from face_detection_amd import runtime
+    from face_detection_amd.runtime import Context, DevArray
+    ctx = Context(0, "own")
+    rng = np.random.default_rng(8)
+    src = [rng.standard_normal((50_000, 4)).astype(F32) for _ in range(4)]
+    dev = [DevArray.from_host(ctx, a) for a in src]
+    held = [d.numpy() for d in dev]                       # four blocks of one size class, all held
+    ptrs = {h.ctypes.data for h in held}
+    assert len(ptrs) == 4
+    for h, a in zip(held, src):
+        np.testing.assert_array_equal(h, a)
+        assert h.flags.writeable and h.flags.c_contiguous and h.base is not None
+    row = held[0][123]                                     # a view keeps its block
+    first = held[0].ctypes.data
+    held[0] = None
+    gc.collect()
+    again = dev[1].numpy()
+    assert again.ctypes.data not in ptrs or again.ctypes.data != first
+    np.testing.assert_array_equal(row, src[0][123])
+    del row
+    gc.collect()
+    reused = dev[2].numpy()                                # now the first block is free again
+    assert reused.ctypes.data == first
+    np.testing.assert_array_equal(reused, src[2])
+    for h, a in zip(held[1:], src[1:]):
+        np.testing.assert_array_equal(h, a)
+    # small and very large results use ordinary memory; the C ABI refuses foreign pointers
+    assert DevArray.from_host(ctx, np.arange(10, dtype=np.int32)).numpy().base is None
+    rc = ctx.lib.ssdbox_host_free(ctypes.c_void_p(12345))
+    assert rc != 0 and b"ssdbox_host_alloc" in ctx.lib.ssdbox_last_error()
+    assert runtime._pinned_pool._outstanding >= 0
+
+
 def test_dlpack_exchange():
     import torch
     from face_detection_amd.runtime import Context, DevArray

@@ -37,8 +37,8 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--gmax", type=int, default=256)
@@ -477,11 +477,13 @@ def main():
     value = images / elapsed
 
     # the two halves on their own (same protocol), for the per-half figures of the metric
-    # (auxiliary figures: at least 200 steps each, so that a short --steps run reads the same rates)
+    # (auxiliary figures: at least 2000 steps each after 200 untimed ones, i.e. 30-40 ms per half, so
+    # that a short --steps run reads the same steady rates: with 200 steps the fill and drain of the
+    # four chains and the first milliseconds after a pause still cost 5-15 %)
     nslots = len(wl.slots)
-    half_steps = max(args.steps, 200)
-    t_match = timed_loop(torch, dist, world, lambda i: wl.match(wl.slots[i % nslots]), half_steps, 20)
-    t_det = timed_loop(torch, dist, world, lambda i: wl.detect(wl.slots[i % nslots]), half_steps, 20)
+    half_steps = max(args.steps, 2000)
+    t_match = timed_loop(torch, dist, world, lambda i: wl.match(wl.slots[i % nslots]), half_steps, 200)
+    t_det = timed_loop(torch, dist, world, lambda i: wl.detect(wl.slots[i % nslots]), half_steps, 200)
 
     # evaluation.py:67 runs the same post-processing with threshold 0: every anchor is a candidate
     thr = args.score_thr

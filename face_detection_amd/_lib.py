@@ -46,6 +46,7 @@ SIGNATURES = {
     "ssdbox_ctx_synchronize": (_i, [_vp]),
     "ssdbox_ctx_set_timing": (_i, [_vp, _i]),
     "ssdbox_ctx_collect_timing": (_i, [_vp, _pf, _pi32]),
+    "ssdbox_ctx_collect_timeline": (_i, [_vp, _vp, _pi32, _pf, _pf, _i, _pi32]),
     "ssdbox_device_count": (_i, []),
     "ssdbox_buf_alloc": (_i, [_vp, ctypes.c_size_t, ctypes.POINTER(_vp)]),
     "ssdbox_buf_free": (_i, [_vp, _vp]),

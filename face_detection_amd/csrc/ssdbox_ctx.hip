@@ -7,6 +7,9 @@
 
 #include <new>
 
+#include <atomic>
+#include <mutex>
+
 #include "ssdbox_internal.h"
 
 static thread_local char g_err[512] = "";
@@ -47,6 +50,36 @@ int ensure_buffer(void **ptr, size_t *cap, size_t need, size_t elem_size, bool z
     if (zero) SSD_CHECK_HIP(hipMemsetAsync(*ptr, 0, want * elem_size, stream));
     return SSDBOX_OK;
 }
+
+// ------------------------------------------------------------------ select kernels in turn
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_turn_mutex;
+int *g_turn[kMaxDevices];
+std::atomic<int> g_ticket[kMaxDevices];
+}  // namespace
+
+int select_turn_buffer(int device, int **turn)
+{
+    SSD_REQUIRE(device >= 0 && device < kMaxDevices, "device %d outside [0, %d)", device, kMaxDevices);
+    std::lock_guard<std::mutex> lock(g_turn_mutex);
+    if (g_turn[device] == nullptr) {
+        // 64 ints of header (the number being served) + 64 exit counters 64 bytes apart
+        const size_t bytes = (64 + 64 * 16) * sizeof(int);
+        int *p = nullptr;
+        SSD_CHECK_HIP(hipMalloc((void **)&p, bytes));
+        if (hipMemset(p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+            (void)hipFree(p);
+            set_error("select_turn_buffer: clearing the buffer failed");
+            return SSDBOX_ERR_HIP;
+        }
+        g_turn[device] = p;            // lives until the process ends
+    }
+    *turn = g_turn[device];
+    return SSDBOX_OK;
+}
+
+int select_take_ticket(int device) { return g_ticket[device].fetch_add(1, std::memory_order_relaxed); }
 
 // ----------------------------------------------------------------------------- timing
 bool acquire_events(ssdbox_ctx *ctx, hipEvent_t ev[2])
@@ -226,6 +259,98 @@ extern "C" int ssdbox_ctx_collect_timing(ssdbox_ctx *ctx, float *ms, int32_t *la
     }
     return SSDBOX_OK;
 }
+
+// Like collect, but keeps every launch apart: stage, begin and end in milliseconds after the first
+// recorded launch of `ref` (the same context, or another one of the same device, which keeps its
+// records: the launches of several contexts on one time axis).  Events of one device share a
+// clock, whichever stream they were recorded on.
+extern "C" int ssdbox_ctx_collect_timeline(ssdbox_ctx *ctx, ssdbox_ctx *ref, int32_t *stage, float *begin_ms,
+                                           float *end_ms, int capacity, int32_t *count)
+{
+    SSD_REQUIRE(ctx != nullptr && ref != nullptr && stage != nullptr && begin_ms != nullptr && end_ms != nullptr &&
+                    count != nullptr && capacity >= 0,
+                "ssdbox_ctx_collect_timeline: bad argument");
+    SSD_REQUIRE(ctx->device == ref->device, "ssdbox_ctx_collect_timeline: contexts on different devices");
+    *count = 0;
+    DeviceGuard guard(ctx->device);
+    SSD_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    SSD_CHECK_HIP(hipStreamSynchronize(ref->stream));
+    SSD_REQUIRE(!ref->records.empty(), "ssdbox_ctx_collect_timeline: the reference context has no record");
+    const hipEvent_t origin = ref->records.front().start;
+    hipError_t first = hipSuccess;
+    int n = 0;
+    for (auto &r : ctx->records) {
+        float t0 = 0.0f, t1 = 0.0f;
+        hipError_t e = hipEventElapsedTime(&t0, origin, r.start);
+        if (e == hipSuccess) e = hipEventElapsedTime(&t1, origin, r.stop);
+        if (e == hipSuccess && n < capacity) {
+            stage[n] = r.stage;
+            begin_ms[n] = t0;
+            end_ms[n] = t1;
+            ++n;
+        } else if (e != hipSuccess && first == hipSuccess) {
+            first = e;
+        }
+    }
+    *count = n;
+    // (the records stay: ssdbox_ctx_collect_timing returns the events to the pool)
+    if (first != hipSuccess) {
+        set_error("ssdbox_ctx_collect_timeline: hipEventElapsedTime failed: %s", hipGetErrorString(first));
+        return SSDBOX_ERR_HIP;
+    }
+    return SSDBOX_OK;
+}
+
+#ifdef SSD_EXP_TRACE
+// ------------------------------------------------------------------- trace (experiment build)
+namespace {
+constexpr int kTraceCap = 1 << 18;
+unsigned long long *g_trace_dev = nullptr;
+int g_trace_n = 0;
+struct TraceMeta {
+    int stage;
+    const void *ctx;
+};
+TraceMeta *g_trace_meta = nullptr;
+}  // namespace
+
+// One thread launches in the experiment (no lock).
+unsigned long long *ssd_trace_slot(ssdbox_ctx *ctx, int stage)
+{
+    if (g_trace_dev == nullptr) {
+        if (hipMalloc((void **)&g_trace_dev, (size_t)(kTraceCap + 1) * 2 * sizeof(unsigned long long)) != hipSuccess)
+            abort();
+        (void)hipMemset(g_trace_dev, 0, (size_t)(kTraceCap + 1) * 2 * sizeof(unsigned long long));
+        g_trace_meta = new TraceMeta[kTraceCap];
+    }
+    if (g_trace_n >= kTraceCap) return g_trace_dev + (size_t)kTraceCap * 2;     // overflow slot
+    g_trace_meta[g_trace_n] = {stage, ctx};
+    return g_trace_dev + (size_t)(g_trace_n++) * 2;
+}
+
+extern "C" int ssdbox_debug_trace_reset()
+{
+    g_trace_n = 0;
+    return 0;
+}
+
+// Call after the device is idle.  Returns the number of launches traced since the last reset.
+extern "C" int ssdbox_debug_trace_dump(int32_t *stage, uint64_t *ctx_id, uint64_t *begin, uint64_t *end, int cap)
+{
+    const int n = g_trace_n < cap ? g_trace_n : cap;
+    if (n == 0) return 0;
+    std::vector<unsigned long long> h((size_t)n * 2);
+    if (hipMemcpy(h.data(), g_trace_dev, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess)
+        return -1;
+    for (int i = 0; i < n; ++i) {
+        stage[i] = g_trace_meta[i].stage;
+        ctx_id[i] = (uint64_t)(uintptr_t)g_trace_meta[i].ctx;
+        begin[i] = h[2 * i];
+        end[i] = h[2 * i + 1];
+    }
+    return n;
+}
+#endif
 
 // --------------------------------------------------------------------------- geometry
 extern "C" int ssdbox_geom_create(int device, int img_width, int img_height, int n_layers,

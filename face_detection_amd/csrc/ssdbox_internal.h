@@ -179,24 +179,61 @@ bool acquire_events(ssdbox_ctx *ctx, hipEvent_t ev[2]);
 // two events, which then hold the kernel's own begin and end timestamps: the elapsed time is
 // the kernel's execution time, without the gaps an event pair recorded around it includes.
 template <typename... KArgs, typename... Args>
-void launch_stage(ssdbox_ctx *ctx, int stage, void (*kernel)(KArgs...), dim3 grid, dim3 block,
-                  Args &&...args)
+void launch_stage_lds(ssdbox_ctx *ctx, int stage, void (*kernel)(KArgs...), dim3 grid, dim3 block,
+                      unsigned lds_bytes, Args &&...args)
 {
     hipEvent_t ev[2];
     if (ctx->timing && ctx->records.size() < kMaxTimingRecords && acquire_events(ctx, ev)) {
-        hipExtLaunchKernelGGL<KArgs...>(kernel, grid, block, 0u, ctx->stream, ev[0], ev[1], 0u,
+        hipExtLaunchKernelGGL<KArgs...>(kernel, grid, block, lds_bytes, ctx->stream, ev[0], ev[1], 0u,
                                         static_cast<KArgs>(args)...);
         try {
             ctx->records.push_back({stage, ev[0], ev[1]});
         } catch (...) {               // the launch stays, its timing is dropped
         }
     } else {
-        hipLaunchKernelGGL(kernel, grid, block, 0, ctx->stream, static_cast<KArgs>(args)...);
+        hipLaunchKernelGGL(kernel, grid, block, lds_bytes, ctx->stream, static_cast<KArgs>(args)...);
     }
+}
+
+template <typename... KArgs, typename... Args>
+void launch_stage(ssdbox_ctx *ctx, int stage, void (*kernel)(KArgs...), dim3 grid, dim3 block,
+                  Args &&...args)
+{
+    launch_stage_lds(ctx, stage, kernel, grid, block, 0u, static_cast<Args &&>(args)...);
 }
 
 int ensure_buffer(void **ptr, size_t *cap, size_t need, size_t elem_size, bool zero,
                   hipStream_t stream);
+
+// The turn-taking of the streaming select kernels (ssdbox_detect.hip): one small buffer per
+// device and process (the number being served and the kernels' exit counters, zero at first) and
+// the number of the next launch.
+int select_turn_buffer(int device, int **turn);
+int select_take_ticket(int device);
+
+// Experiment build (-DSSD_EXP_TRACE, profiles/trace_inflight.py): the kernels of the two hot paths
+// stamp their begin (first workgroup) and end (every workgroup; the last store stays) on the
+// device's 100 MHz wall clock into a slot of a trace buffer the host hands out per launch, so the
+// overlap of several batches in flight can be read without a profiler or events in the way.
+// The product build carries none of it.
+#ifdef SSD_EXP_TRACE
+unsigned long long *ssd_trace_slot(ssdbox_ctx *ctx, int stage);
+#define SSD_TRACE_PARAM , unsigned long long *tr
+#define SSD_TRACE_ARG(ctx, stage) , ssd_trace_slot(ctx, stage)
+#define SSD_TRACE_BEGIN(tr)                                                                  \
+    do {                                                                                     \
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) (tr)[0] = wall_clock64(); \
+    } while (0)
+#define SSD_TRACE_END(tr)                                  \
+    do {                                                   \
+        if (threadIdx.x == 0) (tr)[1] = wall_clock64();    \
+    } while (0)
+#else
+#define SSD_TRACE_PARAM
+#define SSD_TRACE_ARG(ctx, stage)
+#define SSD_TRACE_BEGIN(tr)
+#define SSD_TRACE_END(tr)
+#endif
 
 // ---------------------------------------------------------------------------------------
 // Device helpers.

@@ -59,6 +59,7 @@ struct MatchArgs {
     int n_layers;
     int nbox_max;                  // largest n_box of the geometry: row length of the LDS tables
     int rows_max;                  // largest tile height in rows
+    int stage_off;                 // byte offset of the y_true staging areas in the dynamic LDS
     const GeomDev *geom;           // device copy of the geometry (force kernel)
     const float4 *col_tab;         // geometry: cx, w, h of every anchor column (padded)
     const float *cx_tab;
@@ -78,6 +79,9 @@ struct MatchArgs {
     int *match_idx;
     float *match_iou;
     u64 *gkey;
+#ifdef SSD_EXP_TRACE
+    unsigned long long *tr, *tr_force;
+#endif
 };
 
 struct MatchShared {
@@ -138,6 +142,56 @@ SSD_DEV void store_target(const MatchArgs &p, long long row, unsigned off, float
             if (p.match_iou) st_off(p.match_iou + row, off * 4u, iou);
         }
     }
+}
+
+// A run of consecutive y_true rows, one per lane of a group of LANES lanes (32: a half wave, 64:
+// the wave), written as whole 16-byte pieces.  The rows are 24 bytes long, so a lane's own row
+// would go out as three 8-byte pieces at a 24-byte stride and every 128-byte line would reach
+// memory in several partial writes (twice the bytes on the memory side, a third of the store
+// rate).  Instead the group lays its rows out in LDS as they lie in memory (shifted by the run's
+// offset inside its first 16 bytes) and every lane stores aligned 16-byte pieces of the run; a
+// run that starts or ends on an odd multiple of 8 bytes has one 8-byte piece at that end.
+//   region   this group's staging area, 16-byte aligned, LANES * 24 + 16 bytes
+//   gdst     address of the run's first row (the same in every lane of the group, 8-byte aligned)
+//   n_rows   rows of the run (the same in every lane of the group; 0: nothing to store)
+//   l        lane within the group; `have`: this lane holds row l of the run
+// LDS instructions of one wave execute in order, so the group needs no barrier between its
+// writes and its reads, nor before the next run overwrites the area.
+constexpr unsigned kStageBytes32 = 32u * 24u + 16u;
+constexpr unsigned kStageBytes64 = 64u * 24u + 16u;
+template <int LANES>
+SSD_DEV void store_ytrue_run(unsigned char *region, float *gdst, int n_rows, unsigned l, bool have, float conf,
+                             float4 t)
+{
+    const unsigned shift = (unsigned)reinterpret_cast<uintptr_t>(gdst) & 8u;
+    if (have) {
+        const int c = (int)conf;
+        float2 *w = reinterpret_cast<float2 *>(region + shift + 24u * l);
+        w[0] = make_float2(c == 0 ? 1.0f : 0.0f, c == 1 ? 1.0f : 0.0f);
+        w[1] = make_float2(t.x, t.y);
+        w[2] = make_float2(t.z, t.w);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const unsigned end = shift + 24u * (unsigned)n_rows;         // the run is [shift, end) of the area
+    unsigned char *g0 = reinterpret_cast<unsigned char *>(gdst) - shift;   // 16-byte aligned
+    constexpr int kRounds = (LANES * 24 + 8 + 16 * LANES - 1) / (16 * LANES);
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) {
+        const unsigned b = 16u * (l + (unsigned)(r * LANES));
+        if (b >= shift && b + 16u <= end)
+            __builtin_nontemporal_store(*reinterpret_cast<const vf4 *>(region + b), reinterpret_cast<vf4 *>(g0 + b));
+    }
+    if (n_rows > 0) {
+        if (l == 0u && shift != 0u)
+            __builtin_nontemporal_store(*reinterpret_cast<const vf2 *>(region + 8u), reinterpret_cast<vf2 *>(g0 + 8u));
+        if (l == 1u && (end & 8u) != 0u)
+            __builtin_nontemporal_store(*reinterpret_cast<const vf2 *>(region + end - 8u),
+                                        reinterpret_cast<vf2 *>(g0 + end - 8u));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 }
 
 // Ballot compaction of the chunk's boxes that may touch the extent [ex0, ex1] x [ey0, ey1] into
@@ -315,6 +369,8 @@ SSD_DEV void geom_tile(const MatchArgs &p, MatchShared &sm, const MatchLayer &L)
     float2 *s_lwh = reinterpret_cast<float2 *>(match_dyn_lds);
     float *s_cy = reinterpret_cast<float *>(s_lwh + (kListCap + 1) * p.nbox_max);
     float *s_ty0 = s_cy + p.rows_max;
+    // y_true layout: every half wave's staging area for its run of rows (store_ytrue_run)
+    unsigned char *stage = match_dyn_lds + p.stage_off + (t >> 5) * kStageBytes32;
 
     // ---- prologue: everything this workgroup reads from memory, requested together
     const int G = max(min(p.gt_count[img], p.gmax), 1);
@@ -366,6 +422,16 @@ SSD_DEV void geom_tile(const MatchArgs &p, MatchShared &sm, const MatchLayer &L)
     const int a_step = 2 * L.row_anchors;
     const unsigned out_off = rowslot * (unsigned)L.row_anchors + c;
     const int n_groups_here = (rows_here + 2 * R - 1) / (2 * R);
+    const int n_cols = min((int)kTileCols, L.row_anchors - (int)c0);   // anchor columns of this tile
+    // One anchor's result (called by every lane of the wave: the y_true layout stores by runs)
+    auto emit = [&](long long row, bool ok, bool row_ok, float conf, float4 tgt, int idx, float iou) {
+        if (YTRUE) {
+            float *gdst = p.y_true + (row + (long long)(out_off - (lane & 31u))) * 6;
+            store_ytrue_run<32>(stage, gdst, row_ok ? n_cols : 0, lane & 31u, ok, conf, tgt);
+        } else if (ok) {
+            store_target<false, DETAILS>(p, row, out_off, conf, tgt, idx, iou);
+        }
+    };
 
     float best[R];                 // reduce_max / argmax over GT, first maximum wins (:66-67)
     int sel[R];
@@ -467,9 +533,8 @@ SSD_DEV void geom_tile(const MatchArgs &p, MatchShared &sm, const MatchLayer &L)
                     const float acy = s_cy[min(lr0 + (int)rowslot + 2 * i, tile_rows - 1)];
                     const float conf = (best[i] < p.thr) ? 0.0f : labv[i];
                     const float4 tgt = encode_one(make_float4(acx, acy, aw, ah), gb[i], 0.1f, 0.2f);
-                    if (valid[i])
-                        store_target<YTRUE, DETAILS>(p, out_row + (long long)i * a_step, out_off, conf, tgt, sel[i],
-                                                     best[i]);
+                    emit(out_row + (long long)i * a_step, valid[i], lr0 + (int)rowslot + 2 * i < rows_here, conf, tgt,
+                         sel[i], best[i]);
                 }
                 continue;
             }
@@ -501,8 +566,8 @@ SSD_DEV void geom_tile(const MatchArgs &p, MatchShared &sm, const MatchLayer &L)
                         idx = gq;
                     }
                 }
-                if (valid[i])
-                    store_target<YTRUE, DETAILS>(p, out_row + (long long)i * a_step, out_off, conf, tgt, idx, best[i]);
+                emit(out_row + (long long)i * a_step, valid[i], lr0 + (int)rowslot + 2 * i < rows_here, conf, tgt, idx,
+                     best[i]);
             }
         }
         if (n_list != 0) flush_keys(sm, n_list, t, gkey);
@@ -514,6 +579,7 @@ template <bool YTRUE, bool DETAILS, bool MULTI>
 __global__ __launch_bounds__(kBlock, 5) void match_geom_kernel(const MatchArgs p)
 {
     __shared__ MatchShared sm;
+    SSD_TRACE_BEGIN(p.tr);
     const int tile = blockIdx.x;
     int m = 0;                             // tile ranges run from the last layer to the first
 #pragma unroll
@@ -523,6 +589,7 @@ __global__ __launch_bounds__(kBlock, 5) void match_geom_kernel(const MatchArgs p
         geom_tile<YTRUE, DETAILS, MULTI, 1>(p, sm, L);
     else
         geom_tile<YTRUE, DETAILS, MULTI, kRowsPerThread>(p, sm, L);
+    SSD_TRACE_END(p.tr);
 }
 
 // Materialised anchor array: a workgroup owns 256 consecutive anchors, one per thread.
@@ -598,13 +665,21 @@ __global__ __launch_bounds__(kBlock) void match_array_kernel(const MatchArgs p)
     const float4 gb = ld_off<float4>(gt, (unsigned)sel[0] * 16u);
     const float conf = (best[0] < p.thr) ? 0.0f : labv;
     const float4 tgt = encode_one(anc, gb, 0.1f, 0.2f);
-    if (valid) store_target<YTRUE, DETAILS>(p, out_row, out_off, conf, tgt, sel[0], best[0]);
+    if (YTRUE) {
+        // the wave's anchors base .. are one run of rows
+        const int n_rows = max(0, min(64, p.num_anchors - a_first));
+        store_ytrue_run<64>(match_dyn_lds + wave * kStageBytes64, p.y_true + out_row * 6, n_rows, lane, valid, conf,
+                            tgt);
+    } else if (valid) {
+        store_target<false, DETAILS>(p, out_row, out_off, conf, tgt, sel[0], best[0]);
+    }
 }
 
 template <bool GEOM, bool YTRUE>
 __global__ __launch_bounds__(kBlock) void force_kernel(const MatchArgs p)
 {
     __shared__ int s_anc[SSDBOX_MAX_GT];
+    SSD_TRACE_BEGIN(p.tr_force);
     const int t = threadIdx.x;
     const int img = blockIdx.x;
     const int G = max(min(p.gt_count[img], p.gmax), 1);
@@ -661,11 +736,19 @@ __global__ __launch_bounds__(kBlock) void force_kernel(const MatchArgs p)
         const float4 tgt = encode_one(anc, box, 0.1f, 0.2f);
         store_target<YTRUE, true>(p, (long long)img * p.num_anchors + a, 0u, conf, tgt, g, 1.0f);
     }
+    SSD_TRACE_END(p.tr_force);
 }
 
 template <bool GEOM, bool YTRUE>
-int launch_match(ssdbox_ctx *ctx, const MatchArgs &args, int batch, int n_tiles, size_t lds_bytes)
+int launch_match(ssdbox_ctx *ctx, const MatchArgs &args_in, int batch, int n_tiles, size_t lds_bytes)
 {
+#ifdef SSD_EXP_TRACE
+    MatchArgs args = args_in;
+    args.tr = ssd_trace_slot(ctx, SSDBOX_STAGE_MATCH);
+    args.tr_force = ssd_trace_slot(ctx, SSDBOX_STAGE_FORCE);
+#else
+    const MatchArgs &args = args_in;
+#endif
     const dim3 grid(n_tiles, batch);
     const bool details = args.match_idx != nullptr || args.match_iou != nullptr;
     hipEvent_t ev[2] = {nullptr, nullptr};
@@ -717,6 +800,7 @@ int match_common(ssdbox_ctx *ctx, const ssdbox_geom *geom, const float *d_anchor
     SSD_REQUIRE(d_gt_boxes && d_gt_labels && d_gt_count, "match_encode: NULL ground-truth pointer");
     SSD_REQUIRE(d_y_true != nullptr || (d_conf != nullptr && d_locs != nullptr),
                 "match_encode: NULL output pointer");
+    SSD_REQUIRE(reinterpret_cast<uintptr_t>(d_y_true) % 8 == 0, "match_encode: y_true must be 8-byte aligned");
     SSD_REQUIRE(batch >= 1 && batch <= 65535, "match_encode: batch %d outside [1, 65535]", batch);
     SSD_REQUIRE(gmax >= 1 && gmax <= SSDBOX_MAX_GT, "match_encode: gmax %d outside [1, %d]", gmax,
                 SSDBOX_MAX_GT);
@@ -809,6 +893,13 @@ int match_common(ssdbox_ctx *ctx, const ssdbox_geom *geom, const float *d_anchor
         SSD_REQUIRE(args.rows_max <= kBlock, "match_encode: tile of %d rows", args.rows_max);
         lds_bytes = (size_t)(kListCap + 1) * args.nbox_max * sizeof(float2) +
                     (size_t)args.rows_max * (1 + args.nbox_max) * sizeof(float);
+        if (d_y_true != nullptr) {
+            lds_bytes = (lds_bytes + 15) & ~(size_t)15;
+            args.stage_off = (int)lds_bytes;
+            lds_bytes += (size_t)(kBlock / 32) * kStageBytes32;
+        }
+    } else if (d_y_true != nullptr) {
+        lds_bytes = (size_t)(kBlock / 64) * kStageBytes64;
     }
     args.geom = geom ? geom->d_geom : nullptr;
     args.col_tab = geom ? geom->d_col : nullptr;
@@ -840,7 +931,7 @@ int match_common(ssdbox_ctx *ctx, const ssdbox_geom *geom, const float *d_anchor
         rc = d_y_true ? launch_match<true, true>(ctx, args, batch, (int)n_tiles, lds_bytes)
                       : launch_match<true, false>(ctx, args, batch, (int)n_tiles, lds_bytes);
     else
-        rc = d_y_true ? launch_match<false, true>(ctx, args, batch, (int)n_tiles, 0)
+        rc = d_y_true ? launch_match<false, true>(ctx, args, batch, (int)n_tiles, lds_bytes)
                       : launch_match<false, false>(ctx, args, batch, (int)n_tiles, 0);
     ctx->timing = timing;
     if (rc == SSDBOX_OK && !static_scratch) ctx->gkey_dirty = false;

@@ -120,6 +120,17 @@ class Context:
         _lib.check(self.lib.ssdbox_ctx_collect_timing(self.handle, ms, cnt))
         return {name: (float(ms[i]), int(cnt[i])) for i, name in enumerate(_lib.STAGE_NAMES)}
 
+    def collect_timeline(self, ref=None, capacity=1 << 16):
+        """[(stage name, begin ms, end ms)] of every launch recorded since the last collect_timing,
+        on the time axis of `ref`'s first recorded launch (this context's when ref is None)."""
+        stage = (ctypes.c_int32 * capacity)()
+        t0 = (ctypes.c_float * capacity)()
+        t1 = (ctypes.c_float * capacity)()
+        n = ctypes.c_int32(0)
+        _lib.check(self.lib.ssdbox_ctx_collect_timeline(self.handle, (ref or self).handle, stage, t0, t1,
+                                                        capacity, ctypes.byref(n)))
+        return [(_lib.STAGE_NAMES[stage[i]], float(t0[i]), float(t1[i])) for i in range(n.value)]
+
     def selftest(self, x_log, expect_log, x_exp, expect_exp):
         arrs = [np.ascontiguousarray(a, np.float32) for a in (x_log, expect_log, x_exp, expect_exp)]
         n = len(arrs[0])

@@ -71,6 +71,13 @@ int ssdbox_ctx_synchronize(ssdbox_ctx *ctx);            /* blocks the host */
  * launches[SSDBOX_NUM_STAGES] and clears the records. */
 int ssdbox_ctx_set_timing(ssdbox_ctx *ctx, int enabled);
 int ssdbox_ctx_collect_timing(ssdbox_ctx *ctx, float *ms, int32_t *launches);
+/* The same records launch by launch (a profiling aid; the reference has no counterpart): stage,
+ * begin and end of up to `capacity` recorded launches in milliseconds after the first recorded
+ * launch of `ref`, which may be `ctx` itself or another context of the same device, so that the
+ * launches of several contexts in flight can be put on one time axis.  Blocks until both
+ * contexts' streams are idle; the records stay until ssdbox_ctx_collect_timing clears them. */
+int ssdbox_ctx_collect_timeline(ssdbox_ctx *ctx, ssdbox_ctx *ref, int32_t *stage, float *begin_ms,
+                                float *end_ms, int capacity, int32_t *count);
 
 /* ---- buffers: what a host binding needs to exchange arrays without any other GPU library ---- */
 /* The reference's callers pass numpy arrays (utils/datasets.py:130-152) and tf.Tensors

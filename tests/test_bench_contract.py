@@ -30,4 +30,10 @@ def test_bench_prints_the_contract_line():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     c = d["cpu_baseline"]
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(c) and c["kind"] == "port" and c["cores"] == 1
-    assert d["parity"] == {"images": 1, "match_mask_exact": 1, "nms_kept_exact": 1, "floats_close": 1}
+    assert d["parity"] == {"images": 1, "match_mask_exact": 1, "nms_kept_exact": 1, "floats_close": 1,
+                           "ytrue_equals_conf_locs": 1}
+    # no per-kernel figure above its own roofline; latency-bound kernels carry no fraction
+    for k, v in d["roofline_kernels"].items():
+        assert v["frac"] is None or 0.0 < v["frac"] <= 1.0, (k, v)
+    assert d["timed_steps"] >= 2000 and d["value_requested_region"] > 0
+    assert d["config"]["input_sets"] * 24 * d["config"]["anchors"] * 32 > 256 * 2 ** 20

@@ -134,7 +134,7 @@ def test_bench_two_rank_rehearsal_on_one_gpu():
     env = dict(os.environ, SSDBOX_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"),
-           "--gpus", "2", "--steps", "8", "--warmup", "8", "--no-cpu-baseline", "--seeds", "1", "--no-stress-leg"]
+           "--gpus", "2", "--steps", "8", "--warmup", "8", "--cpu-images", "2", "--seeds", "1", "--no-stress-leg"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -144,3 +144,7 @@ def test_bench_two_rank_rehearsal_on_one_gpu():
     assert d["allgather_detections_ms"] > 0
     assert d["allgather_equals_local_recompute"] is True
     assert d["config"]["parallelism"] == "image-sharded x2"
+    # lines of more than one rank carry the (reduced) CPU baseline and the parity gate too
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] == 1
+    assert all(v == d["parity"]["images"] == 2 for v in d["parity"].values())
+    assert d["roofline"]["frac"] > 0

@@ -7,9 +7,6 @@
 
 #include <new>
 
-#include <atomic>
-#include <mutex>
-
 #include "ssdbox_internal.h"
 
 static thread_local char g_err[512] = "";
@@ -50,36 +47,6 @@ int ensure_buffer(void **ptr, size_t *cap, size_t need, size_t elem_size, bool z
     if (zero) SSD_CHECK_HIP(hipMemsetAsync(*ptr, 0, want * elem_size, stream));
     return SSDBOX_OK;
 }
-
-// ------------------------------------------------------------------ select kernels in turn
-namespace {
-constexpr int kMaxDevices = 64;
-std::mutex g_turn_mutex;
-int *g_turn[kMaxDevices];
-std::atomic<int> g_ticket[kMaxDevices];
-}  // namespace
-
-int select_turn_buffer(int device, int **turn)
-{
-    SSD_REQUIRE(device >= 0 && device < kMaxDevices, "device %d outside [0, %d)", device, kMaxDevices);
-    std::lock_guard<std::mutex> lock(g_turn_mutex);
-    if (g_turn[device] == nullptr) {
-        // 64 ints of header (the number being served) + 64 exit counters 64 bytes apart
-        const size_t bytes = (64 + 64 * 16) * sizeof(int);
-        int *p = nullptr;
-        SSD_CHECK_HIP(hipMalloc((void **)&p, bytes));
-        if (hipMemset(p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
-            (void)hipFree(p);
-            set_error("select_turn_buffer: clearing the buffer failed");
-            return SSDBOX_ERR_HIP;
-        }
-        g_turn[device] = p;            // lives until the process ends
-    }
-    *turn = g_turn[device];
-    return SSDBOX_OK;
-}
-
-int select_take_ticket(int device) { return g_ticket[device].fetch_add(1, std::memory_order_relaxed); }
 
 // ----------------------------------------------------------------------------- timing
 bool acquire_events(ssdbox_ctx *ctx, hipEvent_t ev[2])

@@ -19,7 +19,6 @@
 //   4. nms_scan_kernel   one workgroup per image, one thread per ranked box: bands of 64
 //      boxes are resolved in order, inside a band by rounds of ballots; kept boxes are
 //      compacted in rank order into the detection rows.
-#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -36,7 +35,7 @@ constexpr int kLimit = 1024;                // ranked boxes per image on the fas
 constexpr int kBigLimit = SSDBOX_MAX_NMS_LIMIT;   // ... on the general path (sequential greedy loop)
 constexpr int kBigRanks = kBigLimit / 1024;
 constexpr int kWords = kLimit / 64;
-constexpr int kCap = 4096;                 // keys the top-k kernel stages in LDS
+constexpr int kCap = 8192;                 // keys the top-k kernel stages in LDS
 constexpr int kBucketMax = 256;            // bucket size resolved by direct ranking
 constexpr int kBins = 2048;
 constexpr int kTopkBlock = 1024;
@@ -90,23 +89,21 @@ SSD_DEV int compact_rows6(const float4 (&v)[6], unsigned f0, unsigned nf, float 
     return off;
 }
 
-// DEPTH: items whose loads are in flight ahead of the one being compacted (6 KiB each per wave).
-template <bool LOGITS, int DEPTH>
-__global__ __launch_bounds__(1024) void select_rows6_kernel(const float4 *__restrict__ y, int n,
+template <bool LOGITS>
+__global__ __launch_bounds__(kSelBlock) void select_rows6_kernel(const float4 *__restrict__ y, int n,
                                                                  float thr, u64 *__restrict__ cand,
                                                                  int *__restrict__ seg_count, int nseg,
                                                                  int n_items, unsigned nseg_magic SSD_TRACE_PARAM)
 {
     SSD_TRACE_BEGIN(tr);
     const int lane = threadIdx.x & 63;
-    const int wpb = (int)blockDim.x >> 6;              // waves per workgroup
-    const int stride = (int)gridDim.x * wpb;
-    int item = blockIdx.x * wpb + (threadIdx.x >> 6);
+    const int stride = (int)gridDim.x * (kSelBlock / 64);
+    int item = blockIdx.x * (kSelBlock / 64) + (threadIdx.x >> 6);
+    if (item >= n_items) return;
     const unsigned nf = (unsigned)n / 2u * 3u;
     const u64 lt = (1ull << lane) - 1ull;
 
     auto fetch = [&](int it, float4 (&v)[6]) {
-        if (it >= n_items) return;
         const int img = udiv_magic(it, nseg, nseg_magic);
         const int seg = it - img * nseg;
         const float4 *src = y + (long long)img * nf;
@@ -117,122 +114,22 @@ __global__ __launch_bounds__(1024) void select_rows6_kernel(const float4 *__rest
             v[k] = (f < nf) ? src[f] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    auto compact = [&](int it, const float4 (&v)[6]) {
-        const int img = udiv_magic(it, nseg, nseg_magic);
-        const int seg = it - img * nseg;
+
+    float4 v[6];
+    fetch(item, v);
+    while (true) {
+        const int next = item + stride;
+        float4 vn[6];
+        if (next < n_items) fetch(next, vn);
+        const int img = udiv_magic(item, nseg, nseg_magic);
+        const int seg = item - img * nseg;
         const unsigned f0 = (unsigned)seg * 384u + (unsigned)lane;
-        const int off = compact_rows6<LOGITS>(v, f0, nf, thr, cand + (long long)it * kSeg, lt, [](u64) {});
-        if (lane == 0) seg_count[it] = off;
-    };
-
-    // a ring of DEPTH + 1 register buffers, rotated by unrolling
-    float4 v[DEPTH + 1][6];
+        const int off = compact_rows6<LOGITS>(v, f0, nf, thr, cand + (long long)item * kSeg, lt, [](u64) {});
+        if (lane == 0) seg_count[item] = off;
+        if (next >= n_items) break;
+        item = next;
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d) fetch(item + d * stride, v[d]);
-    while (item < n_items) {
-#pragma unroll
-        for (int r = 0; r <= DEPTH; ++r) {
-            if (item < n_items) {
-                fetch(item + DEPTH * stride, v[(r + DEPTH) % (DEPTH + 1)]);
-                compact(item, v[r]);
-            }
-            item += stride;
-        }
-    }
-    SSD_TRACE_END(tr);
-}
-
-// The select kernel of the usual calls (head rows, a threshold that few anchors pass).  Several
-// batches are in flight on different streams, and what their chains cost is decided by how the
-// streaming kernels of different batches meet on the chip: two that run at the same time split
-// the memory bandwidth and finish together, the per-image kernels behind them then run together
-// too and leave the memory idle, and the batches stay in lock step (measured: four batches in
-// flight spend 40 % of the time with no streaming kernel running).  So the select kernels of one
-// process take turns: the host numbers them in launch order, a workgroup waits until the number
-// being served is its kernel's, and the last workgroup of a kernel to leave passes the turn on.
-// First come, first served at full bandwidth; the chains of the batches interleave instead of
-// marching together.
-//   The turn is a hint, not a lock: a workgroup that has waited kTurnSpins polls goes ahead
-// anyway (a kernel whose predecessor sits behind other work on its own stream), so every
-// workgroup ends whatever happens to the others, and the result never depends on the order.
-//   A waiting kernel must not stand in the way of the per-image kernels of other batches: one
-// workgroup of four waves per CU, no LDS, and few registers - only the scores are loaded (one
-// dword per anchor at the rows' 24-byte stride: the same cache lines as whole-row loads, a sixth
-// of the registers), four items (1024 anchors per wave) in flight.
-constexpr int kTurnDepth = 4;
-constexpr int kTurnSpins = 600;            // polls of about 50 ns each before a workgroup stops waiting
-constexpr int kTurnSlots = 64;             // exit counters, taken in turn by consecutive kernels
-
-template <bool LOGITS>
-__global__ __launch_bounds__(kSelBlock) void select_rows6_turn_kernel(const float *__restrict__ y, int n, float thr,
-                                                                      u64 *__restrict__ cand,
-                                                                      int *__restrict__ seg_count, int nseg,
-                                                                      int n_items, unsigned nseg_magic,
-                                                                      int *__restrict__ turn, int ticket SSD_TRACE_PARAM)
-{
-    if (threadIdx.x == 0) {
-        int spins = 0;
-        // (tickets wrap around: "not yet my turn" is a signed difference)
-        while (__hip_atomic_load(turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ticket < 0 && spins < kTurnSpins) {
-            __builtin_amdgcn_s_sleep(8);
-            ++spins;
-        }
-    }
-    __syncthreads();
-    SSD_TRACE_BEGIN(tr);
-    const int lane = threadIdx.x & 63;
-    const int stride = (int)gridDim.x * (kSelBlock / 64);
-    const u64 lt = (1ull << lane) - 1ull;
-    for (int item = blockIdx.x * (kSelBlock / 64) + (threadIdx.x >> 6); item < n_items; item += stride * kTurnDepth) {
-        float sc[kTurnDepth][4], bg[kTurnDepth][4];
-        // every load is issued whatever the item and the anchor are, at an address clamped into
-        // the batch: straight-line code, all of the loads in flight together
-#pragma unroll
-        for (int d = 0; d < kTurnDepth; ++d) {
-            const int it = min(item + d * stride, n_items - 1);
-            const int img = udiv_magic(it, nseg, nseg_magic);
-            const int seg = it - img * nseg;
-            const float *rows = y + (long long)img * n * 6;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int i = min(seg * kSeg + k * 64 + lane, n - 1);
-                sc[d][k] = rows[(long long)i * 6 + 1];
-                if (LOGITS) bg[d][k] = rows[(long long)i * 6];
-            }
-        }
-#pragma unroll
-        for (int d = 0; d < kTurnDepth; ++d) {
-            const int it = item + d * stride;
-            if (it >= n_items) break;
-            const int img = udiv_magic(it, nseg, nseg_magic);
-            const int seg = it - img * nseg;
-            u64 *out = cand + (long long)it * kSeg;
-            int off = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int i = seg * kSeg + k * 64 + lane;
-                const float score = LOGITS ? softmax_face(bg[d][k], sc[d][k]) : sc[d][k];
-                const bool pass = (i < n) && (score > thr);        // strict >, NaN fails
-                const u64 bal = __ballot(pass);
-                if (pass) out[off + __popcll(bal & lt)] = rank_key(score, (uint32_t)i);
-                off += __popcll(bal);
-            }
-            if (lane == 0) seg_count[it] = off;
-        }
-    }
-    // the last workgroup to leave passes the turn on (never backwards: a kernel that ran out of
-    // turn may finish after its successors)
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int *done = turn + 64 + (ticket & (kTurnSlots - 1)) * 16;
-        if (atomicAdd(done, 1) == (int)gridDim.x - 1) {
-            __hip_atomic_store(done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            int cur = __hip_atomic_load(turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            while (cur - (ticket + 1) < 0 &&
-                   !__hip_atomic_compare_exchange_strong(turn, &cur, ticket + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                         __HIP_MEMORY_SCOPE_AGENT)) {
-            }
-        }
+        for (int k = 0; k < 6; ++k) v[k] = vn[k];
     }
     SSD_TRACE_END(tr);
 }
@@ -570,40 +467,49 @@ SSD_DEV void for_each_candidate(const u64 *__restrict__ cand, const int *__restr
     }
 }
 
-// Shared memory of the top-k selection.  RANKS: ranked boxes per thread.  1: up to 1024 ranks,
-// sorted in registers (the path every caller of the reference takes: limit 1000 at
-// inference.py:60, 200 by default).  kBigRanks: up to kBigLimit ranks, sorted in LDS (`big`).
+// RANKS: ranked boxes per thread.  1: up to 1024 ranks, sorted in registers (the path every
+// caller of the reference takes: limit 1000 at inference.py:60, 200 by default).  kBigRanks: up to
+// kBigLimit ranks, sorted in LDS.
 template <int RANKS>
-struct TopkShared {
-    u64 keys[kCap];
-    unsigned int hist[kBins];
-    u64 xchg[2][kTopkBlock];
-    u64 big[RANKS > 1 ? kTopkBlock * RANKS : 1];
-    u64 bucket[kBucketMax];
-    unsigned int wtot[kTopkBlock / 64];
-    unsigned int sel[3];
-    int count, count2;
-};
-
-// The `limit` largest candidate keys of image `img`, sorted descending: returns their number K
-// (also stored in p.keff); with RANKS == 1 thread t holds the key of rank t in `key` (0 past the
-// sorted keys), otherwise sh.big holds them in rank order.  Ends without a barrier after the
-// last access to `sh`: a caller that reuses the memory synchronises first.
-template <int RANKS>
-SSD_DEV int topk_rank(const TopkArgs &p, TopkShared<RANKS> &sh, int img, u64 &key)
+__global__ __launch_bounds__(kTopkBlock) void topk_sort_kernel(const TopkArgs p)
 {
     constexpr int kSortCap = kTopkBlock * RANKS;          // keys the final sort takes
+    __shared__ u64 s_keys[kCap];
+    __shared__ unsigned int s_hist[kBins];
+    __shared__ u64 s_xchg[2][kTopkBlock];
+    __shared__ u64 s_big[RANKS > 1 ? kSortCap : 1];
+    __shared__ u64 s_bucket[kBucketMax];
+    __shared__ unsigned int s_wtot[kTopkBlock / 64];
+    __shared__ unsigned int s_sel[3];
+    __shared__ int s_count, s_count2;
+
+    SSD_TRACE_BEGIN(p.tr);
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = t >> 6;
+    const int img = blockIdx.x;
     const int nseg = p.nseg;
     const u64 *cand = p.cand + (long long)img * nseg * kSeg;
     const int *segc = p.seg_count + (long long)img * nseg;
     const float lo = p.lo, scale = p.scale;
+#ifdef SSD_EXP_STAMPS              // timing experiment (profiles/topk_stamps.py): phase stamps of image 0
+    unsigned long long st[8];
+    int sti = 0;
+#define SSD_STAMP() st[sti++] = wall_clock64()
+#else
+#define SSD_STAMP()
+#endif
+    SSD_STAMP();
 
     // ---- total number of candidates, and where this thread's segments (t, t + 1024, ...) go
     // if everything is staged: the order of the staged keys does not matter
     const int cnt_first = (t < nseg) ? segc[t] : 0;
+    // (requested together with the count: a segment holds 7 keys on average at a 2-3 % pass rate,
+    // so staging every candidate rarely needs a second trip to memory; slots past the count hold
+    // whatever an earlier call left and are not used)
+    u64 first8[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) first8[u] = cand[(long long)min(t, nseg - 1) * kSeg + u];
     unsigned int mine = (unsigned int)cnt_first;
     for (int s = t + kTopkBlock; s < nseg; s += kTopkBlock) mine += (unsigned int)segc[s];
     unsigned int incl = mine;
@@ -611,18 +517,18 @@ SSD_DEV int topk_rank(const TopkArgs &p, TopkShared<RANKS> &sh, int img, u64 &ke
         const unsigned int v = __shfl_up(incl, o);
         if (lane >= o) incl += v;
     }
-    if (lane == 63) sh.wtot[wave] = incl;
+    if (lane == 63) s_wtot[wave] = incl;
     if (t == 0) {
-        sh.count = 0;
-        sh.count2 = 0;
+        s_count = 0;
+        s_count2 = 0;
     }
     __syncthreads();
     int n = 0;
     int stage_pos = (int)(incl - mine);
 #pragma unroll
     for (int w = 0; w < kTopkBlock / 64; ++w) {
-        if (w < wave) stage_pos += (int)sh.wtot[w];
-        n += (int)sh.wtot[w];
+        if (w < wave) stage_pos += (int)s_wtot[w];
+        n += (int)s_wtot[w];
     }
     const int K = min(n, p.limit);
     if (t == 0) p.keff[img] = K;
@@ -630,7 +536,8 @@ SSD_DEV int topk_rank(const TopkArgs &p, TopkShared<RANKS> &sh, int img, u64 &ke
         static_assert(kBins == 2 * kTopkBlock, "two bins per thread");
         reinterpret_cast<uint2 *>(p.hist_clear + (long long)img * kBins)[t] = make_uint2(0u, 0u);
     }
-    if (n == 0) return 0;
+    if (n == 0) return;
+    SSD_STAMP();
 
     Bucket bk;
     bk.use_lin = 0;
@@ -678,23 +585,28 @@ SSD_DEV int topk_rank(const TopkArgs &p, TopkShared<RANKS> &sh, int img, u64 &ke
                     const u64 *src = cand + (long long)s * kSeg;
                     for (int i0 = 0; i0 < cnt; i0 += 8) {
                         u64 key[8];
+                        if (s == t && i0 == 0) {
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) key[u] = src[min(i0 + u, cnt - 1)];
+                            for (int u = 0; u < 8; ++u) key[u] = first8[u];
+                        } else {
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) key[u] = src[min(i0 + u, cnt - 1)];
+                        }
 #pragma unroll
                         for (int u = 0; u < 8; ++u)
-                            if (i0 + u < cnt) sh.keys[pos + i0 + u] = key[u];
+                            if (i0 + u < cnt) s_keys[pos + i0 + u] = key[u];
                     }
                     pos += cnt;
                 }
-                if (t == 0) sh.count = n;
+                if (t == 0) s_count = n;
             } else {
                 for_each_key([&](u64 key) {
                     if (above_bucket(bk, key, lo, scale) || in_bucket(bk, key, lo, scale))
-                        sh.keys[atomicAdd(&sh.count, 1)] = key;
+                        s_keys[atomicAdd(&s_count, 1)] = key;
                 });
             }
             __syncthreads();
-            m_lds = sh.count;           // == n_above + bucket
+            m_lds = s_count;           // == n_above + bucket
             in_lds = true;
         }
         if (in_lds && (m_lds <= kSortCap || bucket <= kBucketMax || bucket == k_rem)) break;
@@ -703,52 +615,52 @@ SSD_DEV int topk_rank(const TopkArgs &p, TopkShared<RANKS> &sh, int img, u64 &ke
         const int dg = next_digit++;
         const int shift = (dg < 5) ? 53 - 11 * dg : 0;
         const unsigned int dmask = (dg < 5) ? 0x7FFu : 0x1FFu;
-        sh.hist[t] = 0u;
-        sh.hist[t + kTopkBlock] = 0u;
+        s_hist[t] = 0u;
+        s_hist[t + kTopkBlock] = 0u;
         __syncthreads();
         if (in_lds) {
             for (int i = t; i < m_lds; i += kTopkBlock) {
-                const u64 key = sh.keys[i];
+                const u64 key = s_keys[i];
                 if (in_bucket(bk, key, lo, scale))
-                    atomicAdd(&sh.hist[dg < 0 ? linear_bin(key, lo, scale)
+                    atomicAdd(&s_hist[dg < 0 ? linear_bin(key, lo, scale)
                                              : (int)((unsigned int)(key >> shift) & dmask)], 1u);
             }
         } else {
             for_each_key([&](u64 key) {
                 if (in_bucket(bk, key, lo, scale))
-                    atomicAdd(&sh.hist[dg < 0 ? linear_bin(key, lo, scale)
+                    atomicAdd(&s_hist[dg < 0 ? linear_bin(key, lo, scale)
                                              : (int)((unsigned int)(key >> shift) & dmask)], 1u);
             });
         }
         __syncthreads();
         // ---- the digit where the count from the top crosses k_rem
-        const unsigned int h0 = sh.hist[2 * t], h1 = sh.hist[2 * t + 1];
+        const unsigned int h0 = s_hist[2 * t], h1 = s_hist[2 * t + 1];
         const unsigned int pair = h0 + h1;
         unsigned int incl = pair;                  // suffix sum over this wave's higher lanes
         for (int o = 1; o < 64; o <<= 1) {
             const unsigned int v = __shfl_down(incl, o);
             if (lane + o < 64) incl += v;
         }
-        if (lane == 0) sh.wtot[wave] = incl;
+        if (lane == 0) s_wtot[wave] = incl;
         __syncthreads();
         unsigned int above1 = incl - pair;         // keys in digits above 2t+1
-        for (int w = wave + 1; w < kTopkBlock / 64; ++w) above1 += sh.wtot[w];
+        for (int w = wave + 1; w < kTopkBlock / 64; ++w) above1 += s_wtot[w];
         const unsigned int above0 = above1 + h1;
         if ((int)above1 < k_rem && (int)(above1 + h1) >= k_rem) {
-            sh.sel[0] = 2 * t + 1;
-            sh.sel[1] = above1;
-            sh.sel[2] = h1;
+            s_sel[0] = 2 * t + 1;
+            s_sel[1] = above1;
+            s_sel[2] = h1;
         }
         if ((int)above0 < k_rem && (int)(above0 + h0) >= k_rem) {
-            sh.sel[0] = 2 * t;
-            sh.sel[1] = above0;
-            sh.sel[2] = h0;
+            s_sel[0] = 2 * t;
+            s_sel[1] = above0;
+            s_sel[2] = h0;
         }
         __syncthreads();
-        const unsigned int digit = sh.sel[0];
-        n_above += (int)sh.sel[1];
-        k_rem -= (int)sh.sel[1];
-        bucket = (int)sh.sel[2];
+        const unsigned int digit = s_sel[0];
+        n_above += (int)s_sel[1];
+        k_rem -= (int)s_sel[1];
+        bucket = (int)s_sel[2];
         if (dg < 0) {
             bk.use_lin = 1;
             bk.lin = (int)digit;
@@ -759,49 +671,51 @@ SSD_DEV int topk_rank(const TopkArgs &p, TopkShared<RANKS> &sh, int img, u64 &ke
         // after the last bit field the keys (unique) are fully resolved: bucket == 1 == k_rem
     }
 
+    SSD_STAMP();
     // ---- the keys to sort: everything staged, or exactly the K largest
-    key = 0ull;                        // padding ranks below every real key
+    u64 key = 0ull;                    // padding ranks below every real key
     int m_sort;
-    u64 *s_out = RANKS > 1 ? sh.big : sh.xchg[0];
+    u64 *s_out = RANKS > 1 ? s_big : s_xchg[0];
     if (m_lds <= kSortCap) {
         m_sort = m_lds;
         if (RANKS == 1) {
-            if (t < m_lds) key = sh.keys[t];
+            if (t < m_lds) key = s_keys[t];
         } else {
-            for (int i = t; i < m_lds; i += kTopkBlock) s_out[i] = sh.keys[i];
+            for (int i = t; i < m_lds; i += kTopkBlock) s_out[i] = s_keys[i];
         }
     } else {
         const bool whole_bucket = (bucket == k_rem);
         for (int i = t; i < m_lds; i += kTopkBlock) {
-            const u64 kk = sh.keys[i];
+            const u64 kk = s_keys[i];
             if (above_bucket(bk, kk, lo, scale)) {
-                s_out[atomicAdd(&sh.count2, 1)] = kk;
+                s_out[atomicAdd(&s_count2, 1)] = kk;
             } else if (in_bucket(bk, kk, lo, scale)) {
-                if (whole_bucket) s_out[atomicAdd(&sh.count2, 1)] = kk;
-                else sh.bucket[atomicAdd(&sh.count, 1) - m_lds] = kk;    // sh.count restarts at m_lds
+                if (whole_bucket) s_out[atomicAdd(&s_count2, 1)] = kk;
+                else s_bucket[atomicAdd(&s_count, 1) - m_lds] = kk;    // s_count restarts at m_lds
             }
         }
         __syncthreads();
         if (!whole_bucket && t < bucket) {
-            const u64 me = sh.bucket[t];
+            const u64 me = s_bucket[t];
             int rank = 0;
-            for (int i = 0; i < bucket; ++i) rank += (sh.bucket[i] > me) ? 1 : 0;
-            if (rank < k_rem) s_out[atomicAdd(&sh.count2, 1)] = me;
+            for (int i = 0; i < bucket; ++i) rank += (s_bucket[i] > me) ? 1 : 0;
+            if (rank < k_rem) s_out[atomicAdd(&s_count2, 1)] = me;
         }
         __syncthreads();
-        m_sort = K;                    // == sh.count2
+        m_sort = K;                    // == s_count2
         if (RANKS == 1) {
             if (t < K) key = s_out[t];
-            __syncthreads();           // sh.xchg is reused by the sort
+            __syncthreads();           // s_xchg is reused by the sort
         }
     }
 
+    SSD_STAMP();
     int P = 64;
     while (P < m_sort) P <<= 1;
     if (RANKS == 1) {
         // ---- bitonic sort, descending, one key per thread
         int phase = 0;
-        SortStep<2, 1>::run(key, t, sh.xchg, phase, P);
+        SortStep<2, 1>::run(key, t, s_xchg, phase, P);
     } else {
         // ---- bitonic sort, descending, in LDS: every step one pass over the P / 2 pairs
         for (int i = m_sort + t; i < P; i += kTopkBlock) s_out[i] = 0ull;
@@ -823,26 +737,17 @@ SSD_DEV int topk_rank(const TopkArgs &p, TopkShared<RANKS> &sh, int img, u64 &ke
         }
     }
 
-    return K;
-}
-
-template <int RANKS>
-__global__ __launch_bounds__(kTopkBlock) void topk_sort_kernel(const TopkArgs p)
-{
-    constexpr int kSortCap = kTopkBlock * RANKS;
-    __shared__ TopkShared<RANKS> sh;
-    SSD_TRACE_BEGIN(p.tr);
-    const int t = threadIdx.x;
-    const int img = blockIdx.x;
-    u64 key = 0ull;
-    const int K = topk_rank<RANKS>(p, sh, img, key);
-    const u64 *s_out = sh.big;
-    if (RANKS > 1) __syncthreads();
+    SSD_STAMP();
     // ---- ranks t, t + 1024, ... below K: decode / gather their boxes
 #pragma unroll
     for (int q = 0; q < RANKS; ++q) {
         const int r = q * kTopkBlock + t;
-        if (r >= K) continue;
+        if (r >= K) {
+            // Ranks past K hold a box of their own (finite, positive area): the mask kernel reads a
+            // tile's boxes without waiting for K, and what it computes for such a rank is never used.
+            if (RANKS == 1) p.sboxes[(long long)img * kSortCap + r] = make_float4(-2.0f, -2.0f, -1.0f, -1.0f);
+            continue;
+        }
         if (RANKS > 1) key = s_out[r];
         const uint32_t idx = 0xFFFFFFFFu - (uint32_t)key;
         float4 box;
@@ -866,6 +771,15 @@ __global__ __launch_bounds__(kTopkBlock) void topk_sort_kernel(const TopkArgs p)
         p.sidx[o] = (int)idx;
     }
     SSD_TRACE_END(p.tr);
+#ifdef SSD_EXP_STAMPS
+    __builtin_amdgcn_s_waitcnt(0);
+    SSD_STAMP();
+    if (img == 0 && t == 0)
+        printf("topk img0 n=%d K=%d m_lds=%d  count %.2f  stage+select %.2f  extract %.2f  sort %.2f  gather+store %.2f us\n",
+               n, K, m_lds, (st[1] - st[0]) * 0.01, (st[2] - st[1]) * 0.01, (st[3] - st[2]) * 0.01,
+               (st[4] - st[3]) * 0.01, (st[5] - st[4]) * 0.01);
+#endif
+#undef SSD_STAMP
 }
 
 // ---------------------------------------------------------------------------- NMS mask
@@ -899,17 +813,18 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float4 *__restrict__
     __shared__ unsigned short s_pair[kPairCap];
     __shared__ u64 s_res[64];
     const int img = blockIdx.y;
-    const int K = keff[img];
     int rb = 0;                        // band of later boxes; word of earlier boxes cw <= rb
     while ((rb + 1) * (rb + 2) / 2 <= (int)blockIdx.x) ++rb;
     const int cw = (int)blockIdx.x - rb * (rb + 1) / 2;
-    if (rb * 64 >= K) return;
     const int lane = threadIdx.x;
     const float4 *boxes = sboxes + (long long)img * kLimit;
     const int i = cw * 64 + lane;
-    const float4 ib = boxes[min(i, K - 1)];
+    // one trip to memory: the boxes do not wait for K (ranks past K hold a box of their own)
+    const float4 ib = boxes[i];
+    const float4 jl = boxes[rb * 64 + lane];
+    const int K = keff[img];
+    if (rb * 64 >= K) return;
     const float iarea = box_area(ib, kNmsMaxSize);
-    const float4 jl = boxes[min(rb * 64 + lane, K - 1)];
     const float jarea = box_area(jl, kNmsMaxSize);
     s_jbox[lane] = jl;
     s_jarea[lane] = jarea;
@@ -1015,13 +930,23 @@ __global__ __launch_bounds__(kLimit) void nms_scan_kernel(
     const int lane = t & 63;
     const int w_me = t >> 6;
     const int img = blockIdx.x;
-    const int K = keff[img];
-    const int KW = (K + 63) >> 6;
-
+    // One trip to memory: the mask rows, the box, the score and the index of rank t are all
+    // requested before K arrives (ranks past K read what an earlier call left or the top-k
+    // kernel's padding, and drop it below).
     u64 row[kWords];               // row[c]: earlier boxes of word c that suppress box t
 #pragma unroll
     for (int c = 0; c < kWords; ++c)
-        row[c] = (t < K && c <= w_me) ? mask[((long long)img * kWords + c) * kLimit + t] : 0ull;
+        row[c] = (c <= w_me) ? mask[((long long)img * kWords + c) * kLimit + t] : 0ull;
+    const long long o_me = (long long)img * kLimit + t;
+    const float4 b_me = sboxes[o_me];
+    const float score_me = sscores[o_me];
+    const int idx_me = sidx[o_me];
+    const int K = keff[img];
+    const int KW = (K + 63) >> 6;
+    if (t >= K) {
+#pragma unroll
+        for (int c = 0; c < kWords; ++c) row[c] = 0ull;
+    }
     if (t < kWords) s_kept[t] = 0ull;
     bool removed = (t >= K);
     bool kept_me = false;
@@ -1062,16 +987,15 @@ __global__ __launch_bounds__(kLimit) void nms_scan_kernel(
     }
     if (kept_me) {
         const int pos = before + __popcll(s_kept[w_me] & ((1ull << lane) - 1ull));
-        const long long o = (long long)img * kLimit + t;
-        keep_idx[(long long)img * limit + pos] = sidx[o];
+        keep_idx[(long long)img * limit + pos] = idx_me;
         if (dets != nullptr) {
             // clip to [0,1], scale to the original image, [class, score, box] rows
             // (reference inference.py:73-83)
-            const float4 b = sboxes[o];
+            const float4 b = b_me;
             const float W = img_wh ? img_wh[2 * img] : 1.0f;
             const float H = img_wh ? img_wh[2 * img + 1] : 1.0f;
             float2 *d = reinterpret_cast<float2 *>(dets + ((long long)img * limit + pos) * 6);
-            d[0] = make_float2(1.0f, sscores[o]);
+            d[0] = make_float2(1.0f, score_me);
             d[1] = make_float2(clip0(b.x, 1.0f) * W, clip0(b.y, 1.0f) * H);
             d[2] = make_float2(clip0(b.z, 1.0f) * W, clip0(b.w, 1.0f) * H);
         }
@@ -1087,290 +1011,6 @@ __global__ __launch_bounds__(kLimit) void nms_scan_kernel(
     }
     if (t == 0) count[img] = total;
     SSD_TRACE_END(tr);
-}
-
-// ------------------------------------------------------- top-k + NMS in one launch (fast path)
-// Everything after the select kernel for up to 1024 ranks, one workgroup per image: the top-k
-// selection and sort (topk_rank), the decode of the ranked boxes, the suppression bits and the
-// greedy scan, with the ranked boxes and the bit matrix in LDS instead of global memory.  With
-// several batches in flight next to the streaming kernels every dependent trip to memory costs
-// microseconds and every kernel boundary a few more: this kernel makes two trips (candidate
-// keys, then the ranked boxes' head rows) and one set of stores where the three kernels it
-// replaces (topk_sort_kernel<1>, nms_mask_kernel, nms_scan_kernel) made seven trips and wrote and
-// re-read the ranked boxes and the mask.
-//   The 64 x 64 tiles of (earlier, later) pairs are dealt to the 16 waves in turn; a tile is
-// handled as in nms_mask_kernel (overlap sweep, listed pairs, IoU for the listed pairs only; the
-// plain pair-by-pair loop for tiles with non-finite corners, empty boxes or a negative threshold).
-struct NmsOut {
-    float nms_thr;
-    int limit;
-    const float *img_wh;
-    float *dets;
-    int *keep_idx;
-    int *count;
-    int exp_diag;                  // experiment: only the diagonal tiles are computed (wrong results)
-};
-
-constexpr int kTiles = kWords * (kWords + 1) / 2;
-constexpr int kPairCapF = 512;     // listed pairs per tile on the fast path of the fused kernel
-
-struct FusedShared {
-    TopkShared<1> tk;              // dead after the sort: the bit matrix and the pair lists take its place
-    float4 box[kLimit];
-    float area[kLimit];
-    u64 kept[kWords];
-    u64 mask[kTiles * 64];
-};
-static_assert(sizeof(unsigned short) * kPairCapF * (kTopkBlock / 64) <= sizeof(u64) * 2 * kTopkBlock,
-              "the pair lists fit over the sort's exchange buffers");
-
-// One 64 x 64 tile: words of the later boxes 64 * rb + lane over the earlier boxes 64 * cw + bit,
-// into out[lane].  Called by whole waves; `pairs` is the wave's own list.
-SSD_DEV void nms_tile_lds(const float4 *s_box, const float *s_area, int K, int rb, int cw, float thr, int lane,
-                          unsigned short *pairs, u64 *out)
-{
-    const int i = cw * 64 + lane;
-    const int ic = min(i, K - 1), jc = min(rb * 64 + lane, K - 1);
-    const float4 ib = s_box[ic];
-    const float iarea = s_area[ic];
-    const float4 jl = s_box[jc];
-    const float jarea = s_area[jc];
-    const bool zero_suppresses = !(0.0f <= thr);
-    const int jn = min(64, K - rb * 64);
-    const int in = min(64, K - cw * 64);
-
-    // finite coordinates and positive areas on both sides, threshold >= 0
-    const bool plain = (ib.x - ib.x == 0.0f) && (ib.y - ib.y == 0.0f) && (ib.z - ib.z == 0.0f) &&
-                       (ib.w - ib.w == 0.0f) && (jl.x - jl.x == 0.0f) && (jl.y - jl.y == 0.0f) &&
-                       (jl.z - jl.z == 0.0f) && (jl.w - jl.w == 0.0f) && iarea > 0.0f && jarea > 0.0f;
-    if (!zero_suppresses && __ballot(!plain) == 0ull) {
-        // Lane j sweeps the earlier boxes for its later box (broadcast reads, eight in flight).
-        // With finite corners and positive sizes on both sides, min(a.z, b.z) - max(a.x, b.x) > 0
-        // is a.z > b.x && b.z > a.x.
-        unsigned int cand_w[2] = {0u, 0u};             // earlier boxes overlapping later box `lane`
-        const float4 *ibox = s_box + cw * 64;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-#pragma unroll
-            for (int q0 = 0; q0 < 32; q0 += 8) {
-                float4 a[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) a[u] = ibox[32 * h + q0 + u];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const bool ov = (a[u].z > jl.x) & (jl.z > a[u].x) & (a[u].w > jl.y) & (jl.w > a[u].y);   // no short circuit
-                    cand_w[h] |= ov ? (1u << (q0 + u)) : 0u;
-                }
-            }
-        }
-        const unsigned int cand_lo = cand_w[0], cand_hi = cand_w[1];
-        u64 cand = ((u64)cand_hi << 32) | cand_lo;
-        if (in < 64) cand &= (1ull << in) - 1ull;      // (rows past K hold empty boxes)
-        // on the diagonal tile box q is itself lane q: bits at and above it are dropped
-        if (cw == rb) cand &= (1ull << lane) - 1ull;
-        if (lane >= jn) cand = 0ull;
-        const int cnt = __popcll(cand);
-        int incl = cnt;
-        for (int o = 1; o < 64; o <<= 1) {
-            const int v = __shfl_up(incl, o);
-            if (lane >= o) incl += v;
-        }
-        const int total = __builtin_amdgcn_readlane(incl, 63);
-        if (total <= kPairCapF) {
-            out[lane] = 0ull;
-            int e = incl - cnt;
-            u64 w = cand;
-            while (w != 0ull) {
-                const int pos = __builtin_ctzll(w);
-                w &= w - 1ull;
-                pairs[e++] = (unsigned short)((lane << 6) | pos);
-            }
-            // (LDS instructions of one wave execute in order: no barrier inside a wave)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            for (int d = lane; d < total; d += 64) {
-                const int pr = pairs[d];
-                const int j = pr >> 6, ii = pr & 63;
-                const float4 a = ibox[ii], b = s_box[rb * 64 + j];
-                // compute_iou(boxes_a = earlier box, boxes_b = later box), utils/box_utils.py:35-42
-                const float iw = vmin(a.z, b.z) - vmax(a.x, b.x);
-                const float ih = vmin(a.w, b.w) - vmax(a.y, b.y);
-                const float asum = s_area[cw * 64 + ii] + s_area[rb * 64 + j];
-                const float inter = vmin(iw, kNmsMaxSize) * vmin(ih, kNmsMaxSize);
-                const float iou = inter / (asum - inter);
-                if (!(iou <= thr)) atomicOr(&out[j], 1ull << ii);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            return;
-        }
-    }
-
-    u64 word = 0ull;                                   // lane q ends up holding the word of box q
-    for (int q = 0; q < 64; ++q) {
-        // (rows past jn repeat the last box; their words are never used)
-        const int jq = min(rb * 64 + q, K - 1);
-        const float4 jb = s_box[jq];                   // broadcast read
-        // compute_iou(boxes_a = earlier box, boxes_b = later box), utils/box_utils.py:35-42
-        const float iw = vmin(ib.z, jb.z) - vmax(ib.x, jb.x);
-        const float ih = vmin(ib.w, jb.w) - vmax(ib.y, jb.y);
-        const float asum = iarea + s_area[jq];
-        bool sup;
-        if (iw > 0.0f && ih > 0.0f) {
-            const float inter = vmin(iw, kNmsMaxSize) * vmin(ih, kNmsMaxSize);
-            const float iou = inter / (asum - inter);
-            sup = !(iou <= thr);
-        } else {
-            // intersection 0: IoU is +0 over a positive union, NaN over a zero one
-            sup = (asum > 0.0f) ? zero_suppresses : true;
-        }
-        // earlier boxes past K do not exist; on the diagonal tile box q is itself lane q: bits
-        // at and above it are dropped
-        const u64 w = __ballot(sup && i < K && (cw != rb || lane < q));
-        if (lane == q) word = w;
-    }
-    out[lane] = word;
-}
-
-__global__ __launch_bounds__(kTopkBlock) void rank_nms_kernel(const TopkArgs p, const NmsOut o)
-{
-    static_assert(kTopkBlock == kLimit, "one thread per rank");
-    __shared__ FusedShared sm;
-    SSD_TRACE_BEGIN(p.tr);
-    const int t = threadIdx.x;
-    const int lane = t & 63;
-    const int w_me = t >> 6;
-    const int img = blockIdx.x;
-    u64 key = 0ull;
-#ifdef SSD_EXP_STAMPS              // timing experiment: phase stamps of image 0 (profiles/fused_stamps.py)
-    unsigned long long st[8];
-    int sti = 0;
-#define SSD_STAMP() st[sti++] = wall_clock64()
-#else
-#define SSD_STAMP()
-#endif
-    SSD_STAMP();
-    const int K = topk_rank<1>(p, sm.tk, img, key);
-    SSD_STAMP();
-
-    // ---- rank t below K: decode / gather its box
-    const uint32_t idx = 0xFFFFFFFFu - (uint32_t)key;
-    float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
-    float score = 0.0f;
-    if (t < K) {
-        if (p.src.mode == 2) {
-            box = p.src.boxes[idx];
-            score = p.src.scores[idx];
-        } else {
-            const float *row = p.src.y_pred + ((long long)img * p.n_per_image + idx) * 6;
-            score = p.src.logits ? softmax_face(row[0], row[1]) : row[1];
-            const float2 lxy = *reinterpret_cast<const float2 *>(row + 2);
-            const float2 lwh = *reinterpret_cast<const float2 *>(row + 4);
-            const float4 anc = (p.src.mode == 0)
-                                   ? geom_anchor(p.geom, p.src.cx_tab, p.src.cy_tab, (int)idx)
-                                   : p.src.anchors[idx];
-            box = decode_one(anc, make_float4(lxy.x, lxy.y, lwh.x, lwh.y), 0.1f, 0.2f);
-        }
-    }
-    sm.box[t] = box;
-    sm.area[t] = box_area(box, kNmsMaxSize);
-    if (t < kWords) sm.kept[t] = 0ull;
-    __syncthreads();                   // the boxes are in place; the selection's memory is free
-    SSD_STAMP();
-
-    // ---- suppression bits, tile by tile
-    u64 *mask = sm.mask;                                                 // [tile][later box] words
-    unsigned short *pairs = reinterpret_cast<unsigned short *>(&sm.tk.xchg[0][0]) + w_me * kPairCapF;
-    const int KW = (K + 63) >> 6;
-    const int n_tiles = KW * (KW + 1) / 2;
-    for (int tile = w_me; tile < n_tiles; tile += kTopkBlock / 64) {
-        int rb = 0;                    // band of later boxes; word of earlier boxes cw <= rb
-        while ((rb + 1) * (rb + 2) / 2 <= tile) ++rb;
-        const int cw = tile - rb * (rb + 1) / 2;
-        if (o.exp_diag && cw != rb) {
-            mask[tile * 64 + lane] = 0ull;
-            continue;
-        }
-        nms_tile_lds(sm.box, sm.area, K, rb, cw, o.nms_thr, lane, pairs, mask + tile * 64);
-    }
-    __syncthreads();
-    SSD_STAMP();
-
-    // ---- greedy scan (as nms_scan_kernel, rows from LDS)
-    u64 row[kWords];               // row[c]: earlier boxes of word c that suppress box t
-#pragma unroll
-    for (int c = 0; c < kWords; ++c)
-        row[c] = (t < K && c <= w_me) ? mask[(w_me * (w_me + 1) / 2 + c) * 64 + lane] : 0ull;
-    bool removed = (t >= K);
-    bool kept_me = false;
-#pragma unroll
-    for (int w = 0; w < kWords; ++w) {
-        if (w < KW) {
-            if (w_me == w) {
-                const u64 D = row[w];
-                u64 U = __ballot(!removed);
-                u64 kept = 0ull;
-                while (U != 0ull) {
-                    const bool mine = (U >> lane) & 1ull;
-                    const u64 A = __ballot(mine && (D & U) == 0ull);
-                    kept |= A;
-                    const u64 S = __ballot(mine && (D & A) != 0ull);
-                    U &= ~(A | S);
-                }
-                kept_me = (kept >> lane) & 1ull;
-                removed = !kept_me;
-                if (lane == 0) sm.kept[w] = kept;
-            }
-            __syncthreads();
-            if (w_me > w && !removed && (row[w] & sm.kept[w]) != 0ull) removed = true;
-        }
-    }
-    __syncthreads();
-
-    SSD_STAMP();
-    int before = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < kWords; ++w) {
-        const int pc = __popcll(sm.kept[w]);
-        if (w < w_me) before += pc;
-        total += pc;
-    }
-    const int limit = o.limit;
-    if (kept_me) {
-        const int pos = before + __popcll(sm.kept[w_me] & ((1ull << lane) - 1ull));
-        o.keep_idx[(long long)img * limit + pos] = (int)idx;
-        if (o.dets != nullptr) {
-            // clip to [0,1], scale to the original image, [class, score, box] rows
-            // (reference inference.py:73-83)
-            const float W = o.img_wh ? o.img_wh[2 * img] : 1.0f;
-            const float H = o.img_wh ? o.img_wh[2 * img + 1] : 1.0f;
-            float2 *d = reinterpret_cast<float2 *>(o.dets + ((long long)img * limit + pos) * 6);
-            d[0] = make_float2(1.0f, score);
-            d[1] = make_float2(clip0(box.x, 1.0f) * W, clip0(box.y, 1.0f) * H);
-            d[2] = make_float2(clip0(box.z, 1.0f) * W, clip0(box.w, 1.0f) * H);
-        }
-    }
-    if (t >= total && t < limit) {
-        o.keep_idx[(long long)img * limit + t] = -1;
-        if (o.dets != nullptr) {
-            float2 *d = reinterpret_cast<float2 *>(o.dets + ((long long)img * limit + t) * 6);
-            d[0] = make_float2(0.f, 0.f);
-            d[1] = make_float2(0.f, 0.f);
-            d[2] = make_float2(0.f, 0.f);
-        }
-    }
-    if (t == 0) o.count[img] = total;
-#ifdef SSD_EXP_STAMPS
-    __builtin_amdgcn_s_waitcnt(0);
-    SSD_STAMP();
-    if (img == 0 && t == 0)
-        printf("fused img0 K=%d  rank %.2f  gather+decode %.2f  pairs %.2f  scan %.2f  store %.2f us\n", K,
-               (st[1] - st[0]) * 0.01, (st[2] - st[1]) * 0.01, (st[3] - st[2]) * 0.01, (st[4] - st[3]) * 0.01,
-               (st[5] - st[4]) * 0.01);
-#endif
-#undef SSD_STAMP
-    SSD_TRACE_END(p.tr);
 }
 
 // ------------------------------------------------- NMS, general path (more than 1024 ranks)
@@ -1476,37 +1116,6 @@ __global__ __launch_bounds__(kTopkBlock) void nms_greedy_big_kernel(
 }
 
 // -------------------------------------------------------------------------------- host
-// Shape of the streaming select kernel (SSDBOX_SEL_WGS / SSDBOX_SEL_DEPTH override it for
-// experiments): workgroups per CU of its persistent grid (0: one item per wave, as many
-// workgroups as items / 4) and items in flight ahead per wave.
-int env_int(const char *name, int lo, int hi, int dflt)
-{
-    const char *e = getenv(name);
-    if (e == nullptr || *e == 0) return dflt;
-    const int v = atoi(e);
-    return (v >= lo && v <= hi) ? v : dflt;
-}
-int select_wgs_per_cu()
-{
-    static const int v = env_int("SSDBOX_SEL_WGS", 0, 64, 0);
-    return v;
-}
-int select_in_turn()
-{
-    static const int v = env_int("SSDBOX_SEL_TURN", 0, 1, 0);
-    return v;
-}
-int fused_tail()
-{
-    static const int v = env_int("SSDBOX_FUSED_TAIL", 0, 1, 0);
-    return v;
-}
-int select_depth()
-{
-    static const int v = env_int("SSDBOX_SEL_DEPTH", 1, 3, 1);
-    return v;
-}
-
 int ensure_detect_scratch(ssdbox_ctx *ctx, int batch, long long nseg, int rank_cap)
 {
     int rc = ensure_buffer((void **)&ctx->cand, &ctx->cand_cap, (size_t)batch * (size_t)nseg * kSeg,
@@ -1587,6 +1196,8 @@ int run_detect(ssdbox_ctx *ctx, const ScoreLayout &sl, long long n, int batch, f
         const long long n_items = (long long)nseg * batch;
         // (the item -> image division by multiply-high is exact while items * segments < 2^32)
         const bool rows6 = sl.rows6 && n_items < (1ll << 31) / kSeg && n_items * nseg < (1ll << 32);
+        const unsigned pgrid = (unsigned)std::min<long long>((n_items + kSelBlock / 64 - 1) / (kSelBlock / 64),
+                                                             (long long)ctx->num_cus * kSelWgsPerCu);
         const unsigned nseg_magic = nseg > 1 ? (unsigned)(((1ull << 32) + (unsigned)nseg - 1) / (unsigned)nseg) : 0u;
         const float4 *rows = reinterpret_cast<const float4 *>(sl.scores);
         if (rows6 && dense) {
@@ -1599,42 +1210,14 @@ int run_detect(ssdbox_ctx *ctx, const ScoreLayout &sl, long long n, int batch, f
                 launch_stage(ctx, SSDBOX_STAGE_SELECT, select_rows6_hist_kernel<false>, hist_grid, dim3(kSelBlock), rows,
                              (int)n, sl.thr, ctx->cand, ctx->cand_count, nseg, has_range, range_lo, range_scale,
                              ctx->cand_hist);
-        } else if (rows6 && select_in_turn()) {
-            int *turn = nullptr;
-            rc = select_turn_buffer(ctx->device, &turn);
-            if (rc != SSDBOX_OK) return rc;
-            const unsigned sgrid = (unsigned)std::min<long long>((n_items + kSelBlock / 64 - 1) / (kSelBlock / 64),
-                                                                 ctx->num_cus);
-            // (the number is taken right before the launch: nothing that can fail lies between)
-            const int ticket = select_take_ticket(ctx->device);
-            if (sl.logits)
-                launch_stage(ctx, SSDBOX_STAGE_SELECT, select_rows6_turn_kernel<true>, dim3(sgrid), dim3(kSelBlock),
-                             sl.scores, (int)n, sl.thr, ctx->cand, ctx->cand_count, nseg, (int)n_items, nseg_magic, turn,
-                             ticket SSD_TRACE_ARG(ctx, SSDBOX_STAGE_SELECT));
-            else
-                launch_stage(ctx, SSDBOX_STAGE_SELECT, select_rows6_turn_kernel<false>, dim3(sgrid), dim3(kSelBlock),
-                             sl.scores, (int)n, sl.thr, ctx->cand, ctx->cand_count, nseg, (int)n_items, nseg_magic, turn,
-                             ticket SSD_TRACE_ARG(ctx, SSDBOX_STAGE_SELECT));
+        } else if (rows6 && sl.logits) {
+            launch_stage(ctx, SSDBOX_STAGE_SELECT, select_rows6_kernel<true>, dim3(pgrid), dim3(kSelBlock), rows,
+                         (int)n, sl.thr, ctx->cand, ctx->cand_count, nseg, (int)n_items,
+                         nseg_magic SSD_TRACE_ARG(ctx, SSDBOX_STAGE_SELECT));
         } else if (rows6) {
-            // a persistent grid of sel_wgs workgroups per CU with sel_depth items in flight ahead
-            // per wave, or (sel_wgs 0) one item per wave
-            const int wgs = select_wgs_per_cu(), depth = select_depth();
-            const int sel_block = env_int("SSDBOX_SEL_BLOCK", 64, 1024, kSelBlock);
-            const unsigned all_wgs = (unsigned)((n_items + sel_block / 64 - 1) / (sel_block / 64));
-            const unsigned sgrid = wgs > 0 ? std::min<unsigned>(all_wgs, (unsigned)(ctx->num_cus * wgs))
-                                           : std::min<unsigned>(all_wgs, (unsigned)ctx->num_cus * kSelWgsPerCu);
-            void (*kernel)(const float4 *, int, float, u64 *, int *, int, int, unsigned SSD_TRACE_PARAM);
-            if (sl.logits)
-                kernel = depth >= 3 ? select_rows6_kernel<true, 3>
-                                    : depth == 2 ? select_rows6_kernel<true, 2> : select_rows6_kernel<true, 1>;
-            else
-                kernel = depth >= 3 ? select_rows6_kernel<false, 3>
-                                    : depth == 2 ? select_rows6_kernel<false, 2> : select_rows6_kernel<false, 1>;
-            const unsigned lds = (unsigned)env_int("SSDBOX_SEL_LDS", 0, 160 * 1024, 0);
-            if (lds > 0) SSD_CHECK_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            launch_stage_lds(ctx, SSDBOX_STAGE_SELECT, kernel, dim3(sgrid), dim3(sel_block), lds, rows, (int)n, sl.thr,
-                             ctx->cand, ctx->cand_count, nseg, (int)n_items,
-                             nseg_magic SSD_TRACE_ARG(ctx, SSDBOX_STAGE_SELECT));
+            launch_stage(ctx, SSDBOX_STAGE_SELECT, select_rows6_kernel<false>, dim3(pgrid), dim3(kSelBlock), rows,
+                         (int)n, sl.thr, ctx->cand, ctx->cand_count, nseg, (int)n_items,
+                         nseg_magic SSD_TRACE_ARG(ctx, SSDBOX_STAGE_SELECT));
         } else {
             launch_stage(ctx, SSDBOX_STAGE_SELECT, select_strided_kernel, grid, dim3(kSelBlock),
                          sl.scores, sl.img_stride, sl.elem_stride, sl.elem_off, (int)n, sl.thr,
@@ -1672,20 +1255,6 @@ int run_detect(ssdbox_ctx *ctx, const ScoreLayout &sl, long long n, int batch, f
 #ifdef SSD_EXP_TRACE
         a.tr = ssd_trace_slot(ctx, SSDBOX_STAGE_TOPK);
 #endif
-        if (!big && fused_tail()) {
-            NmsOut o;
-            o.nms_thr = nms_thr;
-            o.limit = limit;
-            o.img_wh = d_img_wh;
-            o.dets = d_dets;
-            o.keep_idx = d_keep;
-            o.count = d_count;
-            o.exp_diag = env_int("SSDBOX_EXP_DIAG", 0, 1, 0);
-            launch_stage(ctx, SSDBOX_STAGE_TOPK, rank_nms_kernel, dim3(batch), dim3(kTopkBlock), a, o);
-            SSD_CHECK_HIP(hipGetLastError());
-            if (dense) ctx->hist_dirty = false;
-            return SSDBOX_OK;
-        }
         if (big) launch_stage(ctx, SSDBOX_STAGE_TOPK, topk_sort_kernel<kBigRanks>, dim3(batch), dim3(kTopkBlock), a);
         else launch_stage(ctx, SSDBOX_STAGE_TOPK, topk_sort_kernel<1>, dim3(batch), dim3(kTopkBlock), a);
     }

@@ -205,12 +205,6 @@ void launch_stage(ssdbox_ctx *ctx, int stage, void (*kernel)(KArgs...), dim3 gri
 int ensure_buffer(void **ptr, size_t *cap, size_t need, size_t elem_size, bool zero,
                   hipStream_t stream);
 
-// The turn-taking of the streaming select kernels (ssdbox_detect.hip): one small buffer per
-// device and process (the number being served and the kernels' exit counters, zero at first) and
-// the number of the next launch.
-int select_turn_buffer(int device, int **turn);
-int select_take_ticket(int device);
-
 // Experiment build (-DSSD_EXP_TRACE, profiles/trace_inflight.py): the kernels of the two hot paths
 // stamp their begin (first workgroup) and end (every workgroup; the last store stays) on the
 // device's 100 MHz wall clock into a slot of a trace buffer the host hands out per launch, so the

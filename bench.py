@@ -27,11 +27,9 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak
 
-# HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default); two batch streams
-# that share one run one after the other.  Eight queues leave each of the four batch streams one of
-# its own next to the streams PyTorch creates (measured: 9.2e5 images/s against 8.9e5).  Must be set
-# before the HIP runtime starts.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (4 unless the variable says otherwise).
+# The bench leaves the setting alone and records it: with more than four queues active, the kernels
+# of one queue start tens of microseconds after their predecessors (profiles/micro/chain_stamps.hip).
 
 
 def parse_args():
@@ -49,8 +47,8 @@ def parse_args():
                     help="skip the extra figures on a batch with 256 ground-truth boxes in every image")
     ap.add_argument("--streams", type=int, default=4,
                     help="batches in flight (one stream and context each); HIP maps streams onto "
-                         "GPU_MAX_HW_QUEUES hardware queues (this script asks for 8 unless the variable "
-                         "is set; HIP's own default is 4), more streams than four measured slower")
+                         "GPU_MAX_HW_QUEUES hardware queues (4 by default), more streams than queues "
+                         "share them and measured slower")
     ap.add_argument("--input-sets", type=int, default=4,
                     help="synthetic batches (inputs and outputs in buffers of their own) the timed loops "
                          "rotate through; four are 313 MB of head outputs, more than the 256 MiB "
@@ -740,7 +738,7 @@ def main():
                 "batch_per_gpu": args.batch, "anchors": wl.A, "gt_total_per_batch": gt_tot,
                 "kept_per_batch": n_keep, "batches_in_flight": nslots, "input_sets": wl.n_sets,
                 "input_bytes_in_rotation": int(wl.n_sets * 24 * A * B),
-                "stream_priority": args.stream_priority, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                "stream_priority": args.stream_priority, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "4 (HIP default)"),
                 "parallelism": "image-sharded x%d" % world,
                 "dist_backend": backend, "rccl_ranks": world if backend == "nccl" else 0,
             },

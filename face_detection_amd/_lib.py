@@ -55,7 +55,9 @@ SIGNATURES = {
     "ssdbox_copy_d2d": (_i, [_vp, _vp, _vp, ctypes.c_size_t]),
     "ssdbox_host_alloc": (_i, [ctypes.c_size_t, ctypes.POINTER(_vp)]),
     "ssdbox_host_free": (_i, [_vp]),
-    "ssdbox_dlpack_import": (_i, [_vp, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_i64), _pi32, _pi32, _pi32]),
+    "ssdbox_ctx_get_stream": (_i, [_vp, ctypes.POINTER(_vp)]),
+    "ssdbox_dlpack_import": (_i, [_vp, _vp, ctypes.c_int32, ctypes.POINTER(_vp), ctypes.POINTER(_i64), _pi32, _pi32,
+                                  _pi32]),
     "ssdbox_dlpack_export": (_i, [_vp, _vp, ctypes.c_int32, ctypes.POINTER(_i64), ctypes.c_int32, ctypes.c_int32,
                                   ctypes.POINTER(_vp)]),
     "ssdbox_dlpack_delete": (_i, [_vp]),

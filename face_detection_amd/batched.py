@@ -25,7 +25,9 @@ def _on_context_stream(fn):
     stream then waits for it, with the returned CUDA tensors marked as used there."""
     @functools.wraps(fn)
     def wrapper(*args, context=None, **kwargs):
-        if context is None or isinstance(context.stream, str):
+        if context is None or isinstance(context.stream, str) or not context.is_torch_stream:
+            # (a raw hipStream_t value: the caller orders that stream against its own work; the
+            # call keeps its arrays in library memory on it and never needs torch)
             return fn(*args, context=context, **kwargs)
         torch = _torch()
         current = torch.cuda.current_stream(context.device)
@@ -33,9 +35,6 @@ def _on_context_stream(fn):
         handle = stream.cuda_stream if hasattr(stream, "cuda_stream") else int(stream)
         if handle == current.cuda_stream:
             return fn(*args, context=context, **kwargs)
-        if not isinstance(stream, torch.cuda.Stream):
-            raise ValueError("a context bound to a raw stream handle can only be used while that stream is "
-                             "the current one; bind it to a torch.cuda.Stream instead")
         stream.wait_stream(current)
         with torch.cuda.stream(stream):
             res = fn(*args, context=context, **kwargs)

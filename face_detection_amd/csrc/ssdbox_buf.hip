@@ -15,7 +15,7 @@
 namespace {
 
 constexpr size_t kStageChunk = (size_t)4 << 20;      // bytes per staging slot
-constexpr size_t kCacheLimit = (size_t)1 << 30;      // bytes of freed buffers a context keeps
+constexpr size_t kCacheLimit = (size_t)256 << 20;    // bytes of freed buffers a context keeps
 
 // DLPack's C structures (dlpack.h, DLManagedTensor without version field), restated so that
 // the library has no header dependency.
@@ -263,6 +263,7 @@ extern "C" int ssdbox_buf_alloc(ssdbox_ctx *ctx, size_t bytes, void **d_out)
     SSD_REQUIRE(ctx != nullptr && d_out != nullptr, "ssdbox_buf_alloc: NULL argument");
     DeviceGuard guard(ctx->device);
     SSD_NOTHROW_BEGIN
+    std::lock_guard<std::mutex> lock(ctx->buf_mu);
     return buf_alloc_impl(ctx, bytes, d_out);
     SSD_NOTHROW_END
 }
@@ -273,13 +274,16 @@ extern "C" int ssdbox_buf_free(ssdbox_ctx *ctx, void *d_ptr)
     if (d_ptr == nullptr) return SSDBOX_OK;
     DeviceGuard guard(ctx->device);
     SSD_NOTHROW_BEGIN
-    ctx->buf_free.reserve(ctx->buf_free.size() + 1);
-    const size_t bytes = take_live(ctx, d_ptr);
-    SSD_REQUIRE(bytes != 0, "ssdbox_buf_free: %p was not allocated by this context (or was exported)", d_ptr);
-    if (ctx->buf_cached + bytes <= kCacheLimit) {
-        ctx->buf_free.push_back({d_ptr, bytes});
-        ctx->buf_cached += bytes;
-        return SSDBOX_OK;
+    {
+        std::lock_guard<std::mutex> lock(ctx->buf_mu);
+        ctx->buf_free.reserve(ctx->buf_free.size() + 1);
+        const size_t bytes = take_live(ctx, d_ptr);
+        SSD_REQUIRE(bytes != 0, "ssdbox_buf_free: %p was not allocated by this context (or was exported)", d_ptr);
+        if (ctx->buf_cached + bytes <= kCacheLimit) {
+            ctx->buf_free.push_back({d_ptr, bytes});
+            ctx->buf_cached += bytes;
+            return SSDBOX_OK;
+        }
     }
     SSD_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     SSD_CHECK_HIP(hipFree(d_ptr));
@@ -357,8 +361,8 @@ extern "C" int ssdbox_copy_d2d(ssdbox_ctx *ctx, void *d_dst, const void *d_src, 
     return SSDBOX_OK;
 }
 
-extern "C" int ssdbox_dlpack_import(ssdbox_ctx *ctx, void *dl_managed_tensor, void **d_ptr, int64_t *n_elems,
-                                    int32_t *dtype_code, int32_t *dtype_bits, int32_t *owned)
+extern "C" int ssdbox_dlpack_import(ssdbox_ctx *ctx, void *dl_managed_tensor, int32_t producer_ordered, void **d_ptr,
+                                    int64_t *n_elems, int32_t *dtype_code, int32_t *dtype_bits, int32_t *owned)
 {
     SSD_REQUIRE(ctx != nullptr && dl_managed_tensor != nullptr && d_ptr != nullptr && n_elems != nullptr &&
                     dtype_code != nullptr && dtype_bits != nullptr && owned != nullptr,
@@ -388,7 +392,15 @@ extern "C" int ssdbox_dlpack_import(ssdbox_ctx *ctx, void *dl_managed_tensor, vo
     if (t.device.device_type == kDLROCM) {
         SSD_REQUIRE(t.device.device_id == ctx->device, "ssdbox_dlpack_import: tensor on GPU %d, context on %d",
                     t.device.device_id, ctx->device);
-        *d_ptr = data;                           // zero copy: the caller keeps the producer alive
+        // Zero copy: the caller keeps the producer alive.  The library reads the memory on the
+        // context's stream, which knows nothing of the stream the producer wrote it on: unless the
+        // producer has ordered its work before that stream already (the DLPack stream protocol),
+        // everything pending on the device is waited for here.
+        if (!producer_ordered) {
+            DeviceGuard guard(ctx->device);
+            SSD_CHECK_HIP(hipDeviceSynchronize());
+        }
+        *d_ptr = data;
         return SSDBOX_OK;
     }
     if (t.device.device_type == kDLCPU || t.device.device_type == kDLROCMHost ||
@@ -396,7 +408,11 @@ extern "C" int ssdbox_dlpack_import(ssdbox_ctx *ctx, void *dl_managed_tensor, vo
         DeviceGuard guard(ctx->device);
         SSD_NOTHROW_BEGIN
         const size_t bytes = (size_t)n * (t.dtype.bits / 8);
-        int rc = buf_alloc_impl(ctx, bytes, d_ptr);
+        int rc;
+        {
+            std::lock_guard<std::mutex> lock(ctx->buf_mu);
+            rc = buf_alloc_impl(ctx, bytes, d_ptr);
+        }
         if (rc != SSDBOX_OK) return rc;
         *owned = 1;
         if (bytes != 0) rc = copy_h2d_impl(ctx, *d_ptr, data, bytes);
@@ -417,7 +433,11 @@ extern "C" int ssdbox_dlpack_export(ssdbox_ctx *ctx, void *d_ptr, int32_t ndim, 
     DeviceGuard guard(ctx->device);
     SSD_NOTHROW_BEGIN
     ExportHolder *h = new ExportHolder();
-    const size_t bytes = take_live(ctx, d_ptr);
+    size_t bytes;
+    {
+        std::lock_guard<std::mutex> lock(ctx->buf_mu);
+        bytes = take_live(ctx, d_ptr);
+    }
     if (bytes == 0) {
         delete h;
         set_error("ssdbox_dlpack_export: %p was not allocated by this context", d_ptr);
@@ -426,7 +446,10 @@ extern "C" int ssdbox_dlpack_export(ssdbox_ctx *ctx, void *d_ptr, int32_t ndim, 
     // the consumer may use the memory on any stream: everything this context enqueued is done first
     hipError_t e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
-        ctx->buf_live.push_back({d_ptr, bytes});
+        {
+            std::lock_guard<std::mutex> lock(ctx->buf_mu);
+            ctx->buf_live.push_back({d_ptr, bytes});
+        }
         delete h;
         set_error("ssdbox_dlpack_export: %s", hipGetErrorString(e));
         return SSDBOX_ERR_HIP;

@@ -179,6 +179,13 @@ extern "C" int ssdbox_ctx_set_stream(ssdbox_ctx *ctx, void *stream, int own_stre
     return SSDBOX_OK;
 }
 
+extern "C" int ssdbox_ctx_get_stream(ssdbox_ctx *ctx, void **stream)
+{
+    SSD_REQUIRE(ctx != nullptr && stream != nullptr, "ssdbox_ctx_get_stream: NULL argument");
+    *stream = (void *)ctx->stream;
+    return SSDBOX_OK;
+}
+
 extern "C" int ssdbox_ctx_synchronize(ssdbox_ctx *ctx)
 {
     SSD_REQUIRE(ctx != nullptr, "ssdbox_ctx_synchronize: ctx is NULL");

@@ -5,6 +5,7 @@
 #include <hip/hip_ext.h>
 #include <stdint.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -114,6 +115,9 @@ struct ssdbox_ctx {
 
     // buffer surface (ssdbox_buf.hip): buffers handed out, freed buffers kept for reuse, and the
     // pinned staging ring of the host <-> device copies
+    // (a buffer may be released from another thread than the one that runs the context, e.g. by
+    // a garbage collector: the two lists are guarded by buf_mu)
+    std::mutex buf_mu;
     std::vector<DeviceBuf> buf_live, buf_free;
     size_t buf_cached;
     void *stage[2];

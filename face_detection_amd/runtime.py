@@ -110,6 +110,12 @@ class Context:
     def synchronize(self):
         _lib.check(self.lib.ssdbox_ctx_synchronize(self.handle))
 
+    def stream_handle(self):
+        """The hipStream_t value the context launches on (0: the device's default stream)."""
+        out = ctypes.c_void_p()
+        _lib.check(self.lib.ssdbox_ctx_get_stream(self.handle, ctypes.byref(out)))
+        return int(out.value or 0)
+
     def set_timing(self, enabled):
         _lib.check(self.lib.ssdbox_ctx_set_timing(self.handle, int(bool(enabled))))
 
@@ -285,13 +291,37 @@ class DevArray:
 
     @classmethod
     def from_dlpack(cls, ctx, obj, shape):
-        """Borrows (GPU tensor) or stages (host tensor) what obj.__dlpack__() / a capsule describes."""
-        capsule = obj if type(obj).__name__ == "PyCapsule" else obj.__dlpack__()
+        """Borrows (GPU tensor) or stages (host tensor) what obj.__dlpack__() / a capsule describes.
+
+        A GPU tensor is read in place on the context's stream.  An object with __dlpack__ is given
+        that stream (the DLPack stream protocol: the producer orders its pending work before it);
+        a bare capsule says nothing about its producer's stream, so the import waits for the
+        device to be idle."""
+        ordered = 0
+        if type(obj).__name__ == "PyCapsule":
+            capsule = obj
+        else:
+            capsule = None
+            on_gpu = True
+            try:
+                on_gpu = int(obj.__dlpack_device__()[0]) != 1          # 1: kDLCPU
+            except Exception:
+                pass
+            handle = ctx.stream_handle() if on_gpu else 0
+            if handle:
+                try:
+                    capsule = obj.__dlpack__(stream=handle)
+                    ordered = 1
+                except (TypeError, RuntimeError, ValueError, NotImplementedError):
+                    capsule = None                                     # a producer without the stream argument
+            if capsule is None:
+                capsule = obj.__dlpack__()
         managed = _capsule_get(capsule, b"dltensor")
         ptr, n = ctypes.c_void_p(), ctypes.c_int64()
         code, bits, owned = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
-        _lib.check(ctx.lib.ssdbox_dlpack_import(ctx.handle, ctypes.c_void_p(managed), ctypes.byref(ptr), ctypes.byref(n),
-                                                ctypes.byref(code), ctypes.byref(bits), ctypes.byref(owned)))
+        _lib.check(ctx.lib.ssdbox_dlpack_import(ctx.handle, ctypes.c_void_p(managed), ordered, ctypes.byref(ptr),
+                                                ctypes.byref(n), ctypes.byref(code), ctypes.byref(bits),
+                                                ctypes.byref(owned)))
         kind = {0: "i", 1: "u", 2: "f"}.get(code.value)
         if kind is None or n.value != int(np.prod(shape, dtype=np.int64)):
             if owned.value:

@@ -66,6 +66,8 @@ int ssdbox_ctx_create(int device, void *stream, int own_stream, ssdbox_ctx **out
 int ssdbox_ctx_destroy(ssdbox_ctx *ctx);
 int ssdbox_ctx_set_stream(ssdbox_ctx *ctx, void *stream, int own_stream);
 int ssdbox_ctx_synchronize(ssdbox_ctx *ctx);            /* blocks the host */
+/* The hipStream_t the context launches on (what a DLPack producer is given as `stream`). */
+int ssdbox_ctx_get_stream(ssdbox_ctx *ctx, void **stream);
 /* Per-stage device timing with HIP events on the context's stream.  collect() blocks
  * until the recorded launches finish, adds them up into ms[SSDBOX_NUM_STAGES] and
  * launches[SSDBOX_NUM_STAGES] and clears the records. */
@@ -110,14 +112,18 @@ int ssdbox_copy_d2d(ssdbox_ctx *ctx, void *d_dst, const void *d_src, size_t byte
  *   tensor in GPU memory (kDLROCM, same device) is used in place (*owned = 0: the caller keeps the
  *   producer alive until the work enqueued with it has finished); a tensor in host memory (kDLCPU,
  *   pinned host) is staged into a new buffer (*owned = 1: release it with ssdbox_buf_free).  The
- *   library never calls the tensor's deleter: inputs stay the caller's.
+ *   library never calls the tensor's deleter: inputs stay the caller's.  A borrowed GPU tensor
+ *   is read on the context's stream: pass producer_ordered != 0 only when the producer has
+ *   ordered its pending work before that stream (obj.__dlpack__(stream=<ssdbox_ctx_get_stream>),
+ *   the DLPack stream protocol); with 0 (a capsule of unknown origin, such as
+ *   tf.experimental.dlpack.to_dlpack returns) the call blocks until the device is idle first.
  * ssdbox_dlpack_export: wraps a buffer from ssdbox_buf_alloc as a kDLROCM tensor of the given
  *   shape and dtype (DLPack codes: 0 int, 1 uint, 2 float); ownership of the memory moves to the
  *   tensor, whose deleter frees it.  Blocks until the context's stream has finished, so the
  *   consumer may read on any stream.
  * ssdbox_dlpack_delete: calls the deleter of a tensor nobody consumed. */
-int ssdbox_dlpack_import(ssdbox_ctx *ctx, void *dl_managed_tensor, void **d_ptr, int64_t *n_elems,
-                         int32_t *dtype_code, int32_t *dtype_bits, int32_t *owned);
+int ssdbox_dlpack_import(ssdbox_ctx *ctx, void *dl_managed_tensor, int32_t producer_ordered, void **d_ptr,
+                         int64_t *n_elems, int32_t *dtype_code, int32_t *dtype_bits, int32_t *owned);
 int ssdbox_dlpack_export(ssdbox_ctx *ctx, void *d_ptr, int32_t ndim, const int64_t *shape,
                          int32_t dtype_code, int32_t dtype_bits, void **dl_managed_tensor);
 int ssdbox_dlpack_delete(void *dl_managed_tensor);

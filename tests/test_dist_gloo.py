@@ -1,4 +1,4 @@
-"""Multi-process sharding on CPU (gloo, world sizes 2 and 3): every rank ends up with the
+"""Multi-process sharding on CPU (gloo, world sizes 2, 3 and 8): every rank ends up with the
 detections of every image, bit-identical to a single process over the whole batch."""
 import os
 import socket
@@ -16,7 +16,9 @@ def free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,batch", [(2, 6), (2, 5), (3, 7)])
+# (8, 256) and (8, 250) are the partition of the eight-GPU configuration (256 images, 32 per
+# rank) and an uneven variant of it
+@pytest.mark.parametrize("world,batch", [(2, 6), (2, 5), (3, 7), (8, 256), (8, 250)])
 def test_sharded_detections_all_gather(tmp_path, world, batch):
     out = str(tmp_path / "result")
     port = str(free_port())

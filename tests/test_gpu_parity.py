@@ -87,7 +87,9 @@ def check_match(fda, cfg, boxes, labels, counts, max_size, mode):
 @pytest.mark.parametrize("mode", ["geom", "array"])
 @pytest.mark.parametrize("seed,size,ratios,stress,gmax", [
     (0, 128, "config", False, 32), (1, 128, "model", True, 40), (2, 256, "config", True, 256),
-    (3, 96, "config", True, 300), (4, 64, "model", False, 1)])
+    (3, 96, "config", True, 300), (4, 64, "model", False, 1),
+    # the 512 x 512 image of the plumbing configuration (A = 65 280 / 87 040)
+    (5, 512, "config", False, 256), (6, 512, "model", False, 256)])
 def test_match_encode_small(fda, mode, seed, size, ratios, stress, gmax):
     rng = np.random.default_rng(seed)
     cfg = ssd_config(size, ratios)
@@ -233,6 +235,17 @@ def test_decode_nms_small(fda, mode, thr):
     check_decode_nms(fda, cfg, y, thr, wh, mode)
     check_decode_nms(fda, cfg, y, thr, None, mode, limit=200)
     check_decode_nms(fda, cfg, y, thr, None, mode, limit=7)
+
+
+@pytest.mark.parametrize("ratios", ["config", "model"])
+def test_decode_nms_one_512_image(fda, ratios):
+    """One 512 x 512 image (the plumbing configuration) through decode + NMS, both anchor sets."""
+    rng = np.random.default_rng(21)
+    cfg = ssd_config(512, ratios)
+    boxes, _, counts = S.make_ground_truth(rng, 1, 512, gmax=256)
+    y = S.make_head_outputs(rng, cfg, boxes, counts)
+    check_decode_nms(fda, cfg, y, 0.05, np.array([[1920.0, 1080.0]], F32), "geom")
+    check_decode_nms(fda, cfg, y, 0.0, None, "array")
 
 
 @pytest.mark.parametrize("thr", [0.0, 0.01, -1.0])
@@ -553,8 +566,14 @@ def test_context_on_another_stream_is_ordered(fda):
             n = int(count[b])
             np.testing.assert_array_equal(keep[b, :n].cpu().numpy(), c_idx)
             assert_bits_equal(dets[b, :n].cpu().numpy(), c_dets)
-    with pytest.raises(ValueError):
-        fda.decode_nms_batch(grid, y, 0.05, context=Context(0, side.cuda_stream))   # raw handle, not current
+    # a raw stream handle: numpy in and out, the arrays live in library memory on that stream
+    r_dets, r_keep, r_count = fda.decode_nms_batch(grid, y, 0.05, context=Context(0, side.cuda_stream))
+    assert isinstance(r_dets, np.ndarray)
+    np.testing.assert_array_equal(r_count, count.cpu().numpy())
+    np.testing.assert_array_equal(r_keep, keep.cpu().numpy())
+    assert_bits_equal(r_dets, dets.cpu().numpy())
+    with pytest.raises(ValueError):                            # torch tensors need a torch stream
+        fda.decode_nms_batch(grid, torch.from_numpy(y).cuda(), 0.05, context=Context(0, side.cuda_stream))
 
 
 def test_context_set_stream(fda):

@@ -68,6 +68,15 @@ def test_drop_in_calls_without_torch():
             n = int(count[b])
             assert n == len(c_keep) and np.array_equal(keep[b, :n], c_keep)
             assert np.array_equal(bits(dets[b, :n]), bits(c_dets))
+        # a context bound to a raw hipStream_t value (here: the stream of another context)
+        from face_detection_amd.runtime import Context
+        owner = Context(0, "own")
+        raw = Context(0, owner.stream_handle())
+        assert raw.stream_handle() == owner.stream_handle() and not raw.is_torch_stream
+        d3, k3, c3 = fda.decode_nms_batch(grid, y, 0.05, 0.45, 1000, context=raw)
+        assert np.array_equal(c3, count) and np.array_equal(k3, keep) and np.array_equal(bits(d3), bits(dets))
+        t3 = fda.match_encode_batch(grid, boxes, counts, labels, 256.0, context=raw)
+        assert np.array_equal(t3[0], conf) and np.array_equal(bits(t3[1]), bits(locs))
         big = ssd_config(640)
         gb = anchor_utils.generate_anchors(big)
         bb, lb, cb = S.make_ground_truth(rng, 2, 640, gmax=32)
@@ -165,6 +174,20 @@ def test_dlpack_exchange():
     np.testing.assert_array_equal(z.numpy(), src)
     with pytest.raises(ValueError):
         DevArray.from_dlpack(ctx, t.transpose(0, 1), (5, 7, 4))                  # not contiguous
+    # A tensor whose producer is still running on another stream: the import orders the
+    # context's stream behind it (through __dlpack__(stream=...) for an object, by waiting for
+    # the device for a bare capsule), so the library never reads it half written.
+    big = torch.empty((4096, 4096), dtype=torch.float32, device="cuda")
+    want = torch.from_numpy(src).cuda()
+    for as_capsule in (False, True):
+        late = torch.zeros_like(want)
+        for _ in range(30):
+            big = big @ big * 1e-9                                                # milliseconds of queued work
+        late.copy_(want)                                                         # ... then the value we expect
+        obj = torch.utils.dlpack.to_dlpack(late) if as_capsule else late
+        got = DevArray.from_dlpack(ctx, obj, tuple(late.shape)).numpy()
+        np.testing.assert_array_equal(got, src)
+    torch.cuda.synchronize()
     # export: the consumer owns the memory afterwards
     e = DevArray.from_host(ctx, src)
     back = torch.from_dlpack(e.to_dlpack())

@@ -61,6 +61,46 @@ def test_static_scratch_entry_equals_allocating_entry():
         assert np.array_equal(w.view(np.uint32), g.view(np.uint32))
 
 
+def test_static_scratch_entry_allocates_nothing():
+    """A context that has only ever served ssdbox_match_encode_static: after one warm call the
+    device's free memory does not move over further calls (outputs allocated beforehand), and the
+    results are the allocating entry's, computed on another context."""
+    import torch
+    from face_detection_amd import _lib
+    from face_detection_amd.runtime import Context, geometry_for
+    lib = _lib.load()
+    torch.cuda.set_device(0)
+    size, batch, gmax = 256, 6, 64
+    cfg = ssd_config(size)
+    geom = geometry_for(cfg, 0)
+    A = geom.num_anchors
+    rng = np.random.default_rng(12)
+    boxes, labels, counts = S.make_ground_truth(rng, batch, size, gmax=gmax)
+    d = [torch.from_numpy(x).cuda() for x in (boxes, labels, counts)]
+    want = _run(lib, lib.ssdbox_match_encode, Context(0), geom, A, *d, size)
+    fresh = Context(0, torch.cuda.Stream())                   # never sees the allocating entry
+    conf = torch.empty((batch, A), dtype=torch.float32, device="cuda")
+    locs = torch.empty((batch, A, 4), dtype=torch.float32, device="cuda")
+    midx = torch.empty((batch, A), dtype=torch.int32, device="cuda")
+    miou = torch.empty((batch, A), dtype=torch.float32, device="cuda")
+
+    def call():
+        rc = lib.ssdbox_match_encode_static(fresh.handle, geom.handle, None, A, _p(d[0]), _p(d[1]), _p(d[2]), batch,
+                                            gmax, float(size), 0.5, _p(conf), _p(locs), _p(midx), _p(miou))
+        assert rc == 0, lib.ssdbox_last_error()
+    call()
+    fresh.synchronize()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(5):
+        call()
+    fresh.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free1 == free0, "device memory moved by %d bytes over calls that must not allocate" % (free0 - free1)
+    for w, g in zip(want, (conf, locs, midx, miou)):
+        assert np.array_equal(w.view(np.uint32), g.cpu().numpy().view(np.uint32))
+
+
 def test_static_scratch_entry_rejects_what_does_not_fit():
     import torch
     from face_detection_amd import _lib

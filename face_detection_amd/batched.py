@@ -13,7 +13,7 @@ import functools
 import numpy as np
 
 from . import _lib
-from .runtime import AnchorGrid, Session, _is_torch_tensor, _ptr, _torch
+from .runtime import AnchorGrid, Session, _is_tf_tensor, _is_torch_tensor, _ptr, _torch
 
 
 def _on_context_stream(fn):
@@ -75,7 +75,11 @@ def match_encode_batch(anchors, gt_boxes, gt_count, gt_labels=None, max_size=512
     """
     sess = Session(anchors, gt_boxes, gt_labels, context=context)
     ctx = sess.ctx
-    counts_host = np.asarray(gt_count.cpu() if _is_torch_tensor(gt_count) else gt_count)
+    if _is_torch_tensor(gt_count):
+        gt_count = gt_count.cpu()
+    elif _is_tf_tensor(gt_count):
+        gt_count = gt_count.numpy()
+    counts_host = np.asarray(gt_count)
     boxes, family = sess.put(gt_boxes, np.float32)
     if boxes.dim() != 3 or boxes.shape[2] != 4:
         raise ValueError("gt_boxes must have shape (B, G, 4), got %s" % (tuple(boxes.shape),))

@@ -156,7 +156,7 @@ extern "C" int ssdbox_ctx_destroy(ssdbox_ctx *ctx)
     }
     for (auto &e : ctx->event_pool) (void)hipEventDestroy(e);
     void *bufs[] = {ctx->gkey, ctx->loss_key, ctx->loss_small, ctx->cand, ctx->cand_count, ctx->cand_hist, ctx->sboxes, ctx->sscores,
-                    ctx->sidx, ctx->keff, ctx->mask, ctx->selftest_out};
+                    ctx->sidx, ctx->keff, ctx->mask, ctx->selftest_out, ctx->kept_box, ctx->floor_key};
     for (void *b : bufs)
         if (b != nullptr) (void)hipFree(b);
     free_buffer_state(ctx);

@@ -358,6 +358,11 @@ struct TopkArgs {
     int *sidx;
     int *keff;
     unsigned int *hist_clear;     // not NULL: the image's pruning histogram, zeroed for the next call
+    // General path, ranks taken kBigLimit at a time: this launch ranks the keys that follow the
+    // first rank_offset ones.  floor_key holds, per image, the smallest key an earlier launch
+    // ranked (read when rank_offset > 0: only smaller keys count) and takes this launch's.
+    int rank_offset;
+    u64 *floor_key;
 #ifdef SSD_EXP_TRACE
     unsigned long long *tr;
 #endif
@@ -530,6 +535,10 @@ __global__ __launch_bounds__(kTopkBlock) void topk_sort_kernel(const TopkArgs p)
         if (w < wave) stage_pos += (int)s_wtot[w];
         n += (int)s_wtot[w];
     }
+    // (keys are unique, so the launches before this one ranked exactly the rank_offset largest)
+    const bool later_ranks = RANKS > 1 && p.rank_offset > 0;
+    const u64 ceil_key = later_ranks ? p.floor_key[img] : 0ull;
+    if (later_ranks) n = max(n - p.rank_offset, 0);
     const int K = min(n, p.limit);
     if (t == 0) p.keff[img] = K;
     if (p.hist_clear != nullptr) {
@@ -553,7 +562,10 @@ __global__ __launch_bounds__(kTopkBlock) void topk_sort_kernel(const TopkArgs p)
     // (threshold near 0), by a thread per segment when they hold a few keys each (more
     // candidates than LDS takes only because the image has many anchors).
     const bool dense = n >= nseg * 96;
-    auto for_each_key = [&](auto f) {
+    auto for_each_key = [&](auto f_all) {
+        auto f = [&](u64 key) {
+            if (!later_ranks || key < ceil_key) f_all(key);
+        };
         if (dense) {
             for_each_candidate(cand, segc, nseg, wave, lane, f);
             return;
@@ -575,7 +587,7 @@ __global__ __launch_bounds__(kTopkBlock) void topk_sort_kernel(const TopkArgs p)
     while (true) {
         if (!in_lds && n_above + bucket <= kCap) {
             // ---- stage every key at or above the bucket in LDS
-            if (bucket == n) {
+            if (bucket == n && !later_ranks) {
                 // everything: a thread copies the keys of its own segments, eight loads in
                 // flight at a time (a segment holds 7 keys on average at a 2-3 % pass rate), to
                 // the place the scan above gave it
@@ -738,6 +750,7 @@ __global__ __launch_bounds__(kTopkBlock) void topk_sort_kernel(const TopkArgs p)
     }
 
     SSD_STAMP();
+    if (RANKS > 1 && p.floor_key != nullptr && t == 0) p.floor_key[img] = s_out[K - 1];
     // ---- ranks t, t + 1024, ... below K: decode / gather their boxes
 #pragma unroll
     for (int q = 0; q < RANKS; ++q) {
@@ -1018,21 +1031,45 @@ __global__ __launch_bounds__(kLimit) void nms_scan_kernel(
 // suppressed is kept and suppresses every later box whose IoU with it is not <= thr; one
 // workgroup per image keeps the ranked boxes in LDS and walks the ranks in order.  No caller of
 // the reference reaches this path (limit is 1000 at inference.py:60 and 200 by default): it
-// exists so that any limit up to kBigLimit gives the reference's result, not for speed (one
-// barrier per kept box).
+// exists so that any limit gives the reference's result, not for speed (one barrier per kept
+// box).  More than kBigLimit ranks are taken kBigLimit at a time, one launch each, in rank order:
+// a launch first lets the boxes the earlier launches kept (unclipped, in kept_box) suppress its
+// own, which is what the loop would have done by the time it reaches them, then runs the loop on
+// what is left and appends what it keeps.
+
+// compute_iou(boxes_a = earlier box, boxes_b = later box) > thr, utils/box_utils.py:35-42, :216
+SSD_DEV bool nms_suppresses(float4 ib, float iarea, float4 jb, float jarea, float thr, bool zero_suppresses)
+{
+    const float iw = vmin(ib.z, jb.z) - vmax(ib.x, jb.x);
+    const float ih = vmin(ib.w, jb.w) - vmax(ib.y, jb.y);
+    const float asum = iarea + jarea;
+    if (iw > 0.0f && ih > 0.0f) {
+        const float inter = vmin(iw, kNmsMaxSize) * vmin(ih, kNmsMaxSize);
+        const float iou = inter / (asum - inter);
+        return !(iou <= thr);
+    }
+    // intersection 0: IoU is +0 over a positive union, NaN over a zero one
+    return (asum > 0.0f) ? zero_suppresses : true;
+}
+
 __global__ __launch_bounds__(kTopkBlock) void nms_greedy_big_kernel(
     const float4 *__restrict__ sboxes, const float *__restrict__ sscores, const int *__restrict__ sidx,
-    const int *__restrict__ keff, float thr, int limit, const float *__restrict__ img_wh,
-    float *__restrict__ dets, int *__restrict__ keep_idx, int *__restrict__ count)
+    const int *__restrict__ keff, float thr, int limit, int rank_offset, int last,
+    float4 *__restrict__ kept_box, const float *__restrict__ img_wh, float *__restrict__ dets,
+    int *__restrict__ keep_idx, int *__restrict__ count)
 {
     __shared__ float4 s_box[kBigLimit];
     __shared__ float s_area[kBigLimit];
     __shared__ u64 s_removed[kBigLimit / 64];
     __shared__ u64 s_kept[kBigLimit / 64];
+    __shared__ float4 s_prev[kTopkBlock];
+    __shared__ float s_prev_area[kTopkBlock];
+    constexpr int kPer = kBigLimit / kTopkBlock;
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int img = blockIdx.x;
     const int K = keff[img];
+    const int prev = rank_offset > 0 ? count[img] : 0;     // kept by the launches before this one
     const long long base = (long long)img * kBigLimit;
     for (int r = t; r < K; r += kTopkBlock) {
         const float4 b = sboxes[base + r];
@@ -1045,6 +1082,31 @@ __global__ __launch_bounds__(kTopkBlock) void nms_greedy_big_kernel(
     }
     __syncthreads();
     const bool zero_suppresses = !(0.0f <= thr);
+
+    // ---- boxes kept from earlier ranks come first in the loop: they suppress before any box here
+    for (int i0 = 0; i0 < prev; i0 += kTopkBlock) {
+        const int ni = min(kTopkBlock, prev - i0);
+        if (t < ni) {
+            const float4 b = kept_box[(long long)img * limit + i0 + t];
+            s_prev[t] = b;
+            s_prev_area[t] = box_area(b, kNmsMaxSize);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) {
+            const int j = q * kTopkBlock + t;
+            bool sup = false;
+            if (j < K) {
+                const float4 jb = s_box[j];
+                const float jarea = s_area[j];
+                for (int i = 0; i < ni && !sup; ++i) sup = nms_suppresses(s_prev[i], s_prev_area[i], jb, jarea, thr, zero_suppresses);
+            }
+            const u64 bal = __ballot(sup);
+            if (bal != 0ull && lane == 0) atomicOr(&s_removed[j >> 6], bal);        // j - lane is a multiple of 64
+        }
+        __syncthreads();
+    }
+
     for (int i = 0; i < K; ++i) {
         // (uniform: every thread reads the same word, written before the last barrier)
         if ((s_removed[i >> 6] >> (i & 63)) & 1ull) continue;
@@ -1053,22 +1115,7 @@ __global__ __launch_bounds__(kTopkBlock) void nms_greedy_big_kernel(
         const float iarea = s_area[i];
         for (int j0 = i + 1; j0 < K; j0 += kTopkBlock) {
             const int j = j0 + t;
-            bool sup = false;
-            if (j < K) {
-                const float4 jb = s_box[j];
-                // compute_iou(boxes_a = earlier box, boxes_b = later box), utils/box_utils.py:35-42
-                const float iw = vmin(ib.z, jb.z) - vmax(ib.x, jb.x);
-                const float ih = vmin(ib.w, jb.w) - vmax(ib.y, jb.y);
-                const float asum = iarea + s_area[j];
-                if (iw > 0.0f && ih > 0.0f) {
-                    const float inter = vmin(iw, kNmsMaxSize) * vmin(ih, kNmsMaxSize);
-                    const float iou = inter / (asum - inter);
-                    sup = !(iou <= thr);
-                } else {
-                    // intersection 0: IoU is +0 over a positive union, NaN over a zero one
-                    sup = (asum > 0.0f) ? zero_suppresses : true;
-                }
-            }
+            const bool sup = j < K && nms_suppresses(ib, iarea, s_box[j], s_area[j], thr, zero_suppresses);
             // a wave's 64 boxes j0 + 64 w .. lie in at most two words of the bit set
             const u64 bal = __ballot(sup);
             if (bal != 0ull && lane == 0) {
@@ -1082,27 +1129,32 @@ __global__ __launch_bounds__(kTopkBlock) void nms_greedy_big_kernel(
     }
     __syncthreads();
 
-    // kept boxes in rank order; the rest of the `limit` slots cleared (as the scan kernel does)
-    int total = 0;
+    // kept boxes in rank order behind the earlier launches'; after the last launch the rest of
+    // the `limit` slots cleared (as the scan kernel does)
+    int total = prev;
     for (int w = 0; w < kBigLimit / 64; ++w) total += __popcll(s_kept[w]);
     const float W = img_wh ? img_wh[2 * img] : 1.0f;
     const float H = img_wh ? img_wh[2 * img + 1] : 1.0f;
-    for (int r = t; r < limit; r += kTopkBlock) {
-        if (r < K && ((s_kept[r >> 6] >> (r & 63)) & 1ull)) {
-            int pos = __popcll(s_kept[r >> 6] & ((1ull << (r & 63)) - 1ull));
+    for (int r = t; r < K; r += kTopkBlock) {
+        if ((s_kept[r >> 6] >> (r & 63)) & 1ull) {
+            int pos = prev + __popcll(s_kept[r >> 6] & ((1ull << (r & 63)) - 1ull));
             for (int w = 0; w < (r >> 6); ++w) pos += __popcll(s_kept[w]);
-            keep_idx[(long long)img * limit + pos] = sidx[base + r];
+            const long long o = (long long)img * limit + pos;
+            keep_idx[o] = sidx[base + r];
+            const float4 b = s_box[r];
+            if (!last) kept_box[o] = b;
             if (dets != nullptr) {
                 // clip to [0,1], scale to the original image, [class, score, box] rows
                 // (reference inference.py:73-83)
-                const float4 b = s_box[r];
-                float2 *d = reinterpret_cast<float2 *>(dets + ((long long)img * limit + pos) * 6);
+                float2 *d = reinterpret_cast<float2 *>(dets + o * 6);
                 d[0] = make_float2(1.0f, sscores[base + r]);
                 d[1] = make_float2(clip0(b.x, 1.0f) * W, clip0(b.y, 1.0f) * H);
                 d[2] = make_float2(clip0(b.z, 1.0f) * W, clip0(b.w, 1.0f) * H);
             }
         }
-        if (r >= total) {
+    }
+    if (last) {
+        for (int r = total + t; r < limit; r += kTopkBlock) {
             keep_idx[(long long)img * limit + r] = -1;
             if (dets != nullptr) {
                 float2 *d = reinterpret_cast<float2 *>(dets + ((long long)img * limit + r) * 6);
@@ -1175,6 +1227,17 @@ int run_detect(ssdbox_ctx *ctx, const ScoreLayout &sl, long long n, int batch, f
     const bool big = limit > kLimit;
     int rc = ensure_detect_scratch(ctx, batch, nseg, big ? kBigLimit : kLimit);
     if (rc != SSDBOX_OK) return rc;
+    // ranks beyond kBigLimit: one top-k + NMS launch pair per kBigLimit ranks (no more ranks than
+    // scores exist), the kept boxes and the last ranked key carried from pair to pair
+    const long long ranks_total = std::min<long long>(limit, n);
+    const int n_chunks = big ? (int)((ranks_total + kBigLimit - 1) / kBigLimit) : 1;
+    if (n_chunks > 1) {
+        rc = ensure_buffer((void **)&ctx->kept_box, &ctx->kept_cap, (size_t)batch * (size_t)limit, sizeof(float4),
+                           false, ctx->stream);
+        if (rc != SSDBOX_OK) return rc;
+        rc = ensure_buffer((void **)&ctx->floor_key, &ctx->floor_cap, (size_t)batch, sizeof(u64), false, ctx->stream);
+        if (rc != SSDBOX_OK) return rc;
+    }
     // head scores are softmax outputs: spread the linear bins over (threshold, 1]
     const int has_range = (sl.use_thr && sl.thr >= 0.0f && sl.thr < 1.0f) ? 1 : 0;
     const float range_lo = has_range ? sl.thr : 0.0f;
@@ -1255,14 +1318,25 @@ int run_detect(ssdbox_ctx *ctx, const ScoreLayout &sl, long long n, int batch, f
 #ifdef SSD_EXP_TRACE
         a.tr = ssd_trace_slot(ctx, SSDBOX_STAGE_TOPK);
 #endif
-        if (big) launch_stage(ctx, SSDBOX_STAGE_TOPK, topk_sort_kernel<kBigRanks>, dim3(batch), dim3(kTopkBlock), a);
-        else launch_stage(ctx, SSDBOX_STAGE_TOPK, topk_sort_kernel<1>, dim3(batch), dim3(kTopkBlock), a);
+        if (big) {
+            a.floor_key = n_chunks > 1 ? ctx->floor_key : nullptr;
+            for (int c = 0; c < n_chunks; ++c) {
+                a.rank_offset = c * kBigLimit;
+                a.limit = (int)std::min<long long>(kBigLimit, ranks_total - a.rank_offset);
+                launch_stage(ctx, SSDBOX_STAGE_TOPK, topk_sort_kernel<kBigRanks>, dim3(batch), dim3(kTopkBlock), a);
+                a.hist_clear = nullptr;
+                launch_stage(ctx, SSDBOX_STAGE_NMS_SCAN, nms_greedy_big_kernel, dim3(batch), dim3(kTopkBlock),
+                             ctx->sboxes, ctx->sscores, ctx->sidx, ctx->keff, nms_thr, limit, a.rank_offset,
+                             c == n_chunks - 1 ? 1 : 0, n_chunks > 1 ? ctx->kept_box : nullptr, d_img_wh, d_dets,
+                             d_keep, d_count);
+                SSD_CHECK_HIP(hipGetLastError());
+            }
+        } else {
+            launch_stage(ctx, SSDBOX_STAGE_TOPK, topk_sort_kernel<1>, dim3(batch), dim3(kTopkBlock), a);
+        }
     }
     SSD_CHECK_HIP(hipGetLastError());
-    if (big) {
-        launch_stage(ctx, SSDBOX_STAGE_NMS_SCAN, nms_greedy_big_kernel, dim3(batch), dim3(kTopkBlock), ctx->sboxes,
-                     ctx->sscores, ctx->sidx, ctx->keff, nms_thr, limit, d_img_wh, d_dets, d_keep, d_count);
-    } else {
+    if (!big) {
         const int kw = (limit + 63) / 64;
         launch_stage(ctx, SSDBOX_STAGE_NMS_MASK, nms_mask_kernel, dim3(kw * (kw + 1) / 2, batch), dim3(64),
                      ctx->sboxes, ctx->keff, nms_thr, ctx->mask SSD_TRACE_ARG(ctx, SSDBOX_STAGE_NMS_MASK));
@@ -1290,10 +1364,6 @@ static int decode_nms_common(ssdbox_ctx *ctx, const ssdbox_geom *geom, const flo
     SSD_REQUIRE(d_y_pred && d_dets && d_keep_idx && d_count, "decode_nms: NULL buffer");
     SSD_REQUIRE(batch >= 1 && batch <= 65535, "decode_nms: batch %d outside [1, 65535]", batch);
     SSD_REQUIRE(limit >= 1, "decode_nms: limit %d < 1", limit);
-    if (limit > kBigLimit) {
-        set_error("decode_nms: limit %d above the supported %d", limit, kBigLimit);
-        return SSDBOX_ERR_UNSUPPORTED;
-    }
     // the reference loop never ends for thresholds >= 1 (a box's IoU with itself is <= thr)
     SSD_REQUIRE(nms_threshold < 1.0f, "decode_nms: nms_threshold must be < 1");
     SSD_REQUIRE(score_threshold == score_threshold, "decode_nms: score_threshold is NaN");
@@ -1368,10 +1438,6 @@ extern "C" int ssdbox_compute_nms(ssdbox_ctx *ctx, const float *d_boxes, const f
     }
     SSD_REQUIRE(d_boxes && d_scores && d_keep, "compute_nms: NULL buffer");
     const int k = (int)((n < (int64_t)limit) ? n : (int64_t)limit);
-    if (k > kBigLimit) {
-        set_error("compute_nms: min(limit, n) = %d above the supported %d", k, kBigLimit);
-        return SSDBOX_ERR_UNSUPPORTED;
-    }
     BoxSource src;
     src.mode = 2;
     src.geom = nullptr;

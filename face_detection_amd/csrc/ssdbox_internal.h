@@ -111,6 +111,10 @@ struct ssdbox_ctx {
     unsigned long long *mask;      // (batch, LIMIT, LIMIT/64) suppression bits
     size_t det_cap;                // images
     size_t det_rank_cap;           // ranked boxes per image the buffers above hold
+    float4 *kept_box;              // (batch, limit) boxes kept so far, general path beyond 4096 ranks
+    size_t kept_cap;
+    unsigned long long *floor_key; // (batch) smallest key ranked so far, same path
+    size_t floor_cap;
     int *selftest_out;
 
     // buffer surface (ssdbox_buf.hip): buffers handed out, freed buffers kept for reuse, and the

@@ -33,7 +33,7 @@ extern "C" {
 
 #define SSDBOX_MAX_LAYERS          8   /* predictor layers in one anchor geometry           */
 #define SSDBOX_MAX_BOXES_PER_CELL 16   /* boxes per feature-map cell                        */
-#define SSDBOX_MAX_NMS_LIMIT    4096   /* largest effective pre-NMS top-k, min(limit, N)    */
+#define SSDBOX_MAX_NMS_LIMIT    4096   /* ranks one top-k + NMS launch pair of the general path takes */
 #define SSDBOX_MAX_GT           4096   /* largest ground-truth count per image              */
 #define SSDBOX_STATIC_SCRATCH_BYTES (4u << 20) /* fixed per-GPU scratch of ssdbox_match_encode_static */
 
@@ -196,10 +196,12 @@ int ssdbox_match_encode_ytrue(ssdbox_ctx *ctx, const ssdbox_geom *geom,
  * Outputs: d_dets (batch,limit,6) rows [1, score, xmin, ymin, xmax, ymax] in kept order,
  * zero rows after the count; d_keep_idx (batch,limit) int32 anchor index of each kept box
  * (-1 after the count); d_count (batch) int32.  d_img_wh (batch,2) may be NULL (scale 1).
- * limit must be in [1, SSDBOX_MAX_NMS_LIMIT]; nms_threshold must be < 1.  Up to 1024 ranked boxes
- * per image (the reference's callers use 1000, inference.py:60) the suppression matrix is built by
- * the whole chip; above that one workgroup per image runs the reference's loop as written: same
- * result, roughly ten to fifty times the time. */
+ * limit must be >= 1 (any value: the outputs are sized by it); nms_threshold must be < 1.  Up to
+ * 1024 ranked boxes per image (the reference's callers use 1000, inference.py:60) the suppression
+ * matrix is built by the whole chip; above that one workgroup per image runs the reference's loop
+ * as written, SSDBOX_MAX_NMS_LIMIT ranks per pair of launches (min(limit, A) ranks in all, the
+ * boxes kept so far carried from pair to pair): same result, roughly ten to fifty times the time
+ * per 4096 ranks. */
 int ssdbox_decode_nms(ssdbox_ctx *ctx, const ssdbox_geom *geom, const float *d_anchors,
                       int64_t num_anchors, const float *d_y_pred, int batch,
                       float score_threshold, float nms_threshold, int limit,
@@ -220,7 +222,7 @@ int ssdbox_decode_nms_logits(ssdbox_ctx *ctx, const ssdbox_geom *geom, const flo
 /* utils/box_utils.py:184-222 (compute_nms) on caller-supplied boxes: d_boxes (n,4)
  * corners, d_scores (n).  Writes the kept indices into the input arrays, in kept order,
  * to d_keep (min(limit,n) int32) and their number to d_count (1 int32).  n == 0 yields
- * count 0.  min(limit, n) must not exceed SSDBOX_MAX_NMS_LIMIT (fast up to 1024, see
+ * count 0.  Any limit >= 1 (fast up to min(limit, n) = 1024, the general path above, see
  * ssdbox_decode_nms). */
 int ssdbox_compute_nms(ssdbox_ctx *ctx, const float *d_boxes, const float *d_scores,
                        int64_t n, float nms_threshold, int limit, int32_t *d_keep,

@@ -11,9 +11,9 @@ import face_detection_amd as fda
 from face_detection_amd.utils import anchor_utils
 wl = bench.Workload(args, 0)
 grid = anchor_utils.generate_anchors(wl.cfg)
-y = wl.d_ypred
+y = wl.sets[0]["ypred"] if hasattr(wl, "sets") else wl.d_ypred
 for thr in (0.05, 0.0):
-    for limit in (1000, 1024, 1025, 2000, 4096):
+    for limit in (1000, 1024, 1025, 2000, 4096, 4097, 8192, 20000):
         for _ in range(3):
             out = fda.decode_nms_batch(grid, y, thr, 0.45, limit)
         torch.cuda.synchronize()
@@ -21,5 +21,5 @@ for thr in (0.05, 0.0):
         for _ in range(10):
             out = fda.decode_nms_batch(grid, y, thr, 0.45, limit)
         torch.cuda.synchronize()
-        print("thr %.2f limit %4d: %.3f ms per batch of %d, kept %d" % (thr, limit, (time.perf_counter() - t0) / 10 * 1e3,
+        print("thr %.2f limit %5d: %.3f ms per batch of %d, kept %d" % (thr, limit, (time.perf_counter() - t0) / 10 * 1e3,
                                                                       args.batch, int(out[2].sum())))

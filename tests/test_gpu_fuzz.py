@@ -109,7 +109,7 @@ def test_fuzz_decode_nms(fda, seed):
         y[b, parts[5], 2] = np.nan                            # NaN box
     thr = float(rng.choice([0.05, 0.3, 0.0, -1.0, 0.74]))
     nms_thr = float(rng.choice([0.45, 0.0, 0.9, -0.5]))
-    limit = int(rng.choice([1000, 200, 33, 1]))
+    limit = int(rng.choice([1000, 200, 33, 1, 1500, 4500, 9000], p=[0.4, 0.2, 0.1, 0.1, 0.08, 0.07, 0.05]))
     wh = rng.uniform(50, 3000, (B, 2)).astype(F32)
     for anchors in (grid, anchors_np):
         dets, keep, count = fda.decode_nms_batch(anchors, y, thr, nms_thr, limit, wh)

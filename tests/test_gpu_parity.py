@@ -391,8 +391,8 @@ def test_compute_nms_conventions(fda):
     assert list(nms(b, s, 0.45, 10)) == [4, 1, 2, 0, 5, 3]
     with pytest.raises(ValueError):
         nms(boxes, np.array([.9, .8, .7], F32), 1.0, 10)
-    with pytest.raises(NotImplementedError):
-        nms(many, same, 0.45, 5000)         # min(limit, n) above the library's 4096
+    # all scores equal and more ranks than one launch of the general path takes (4096)
+    np.testing.assert_array_equal(nms(many, same, 0.45, 5000), C.compute_nms(many, same, 0.45, 5000))
 
 
 @pytest.mark.parametrize("n,limit", [(1025, 4096), (3000, 2000), (6000, 3000), (6000, 4096), (20000, 4096)])
@@ -410,6 +410,42 @@ def test_compute_nms_more_than_1024_ranks(fda, n, limit):
         np.testing.assert_array_equal(nms(boxes, scores, thr, limit), C.compute_nms(boxes, scores, thr, limit))
     same = np.full((n,), 0.25, F32)
     np.testing.assert_array_equal(nms(boxes, same, 0.45, limit), C.compute_nms(boxes, same, 0.45, limit))
+
+
+@pytest.mark.parametrize("n,limit", [(4097, 4097), (6000, 5000), (9000, 8192), (9000, 8193), (20000, 20000),
+                                     (13000, 50000)])
+def test_compute_nms_more_than_4096_ranks(fda, n, limit):
+    """Beyond 4096 ranked boxes the general path takes the ranks 4096 at a time, the kept boxes of
+    the earlier ranks suppressing the later ones first: the reference's loop, any limit."""
+    nms = fda.box_utils.compute_nms
+    rng = np.random.default_rng(n + limit)
+    boxes = clustered_boxes(rng, n)
+    boxes[:, :2] += rng.uniform(-0.15, 0.15, (n, 2)).astype(F32)   # spread: thousands of boxes survive
+    boxes[:, 2:] = boxes[:, :2] + rng.uniform(0.01, 0.06, (n, 2)).astype(F32)
+    scores = rng.uniform(0, 1, n).astype(F32)
+    scores[rng.integers(0, n, n // 8)] = F32(0.5)                 # ties across the 4096-rank boundaries
+    boxes[rng.integers(0, n, 20), 2] = boxes[rng.integers(0, n, 20), 0]
+    for thr in (0.45, 0.0):
+        want = C.compute_nms(boxes, scores, thr, limit)
+        np.testing.assert_array_equal(nms(boxes, scores, thr, limit), want)
+    assert len(C.compute_nms(boxes, scores, 0.45, limit)) > 1024
+    same = np.full((n,), 0.25, F32)
+    np.testing.assert_array_equal(nms(boxes, same, 0.45, limit), C.compute_nms(boxes, same, 0.45, limit))
+    # and a smaller call on the same context afterwards
+    np.testing.assert_array_equal(nms(boxes[:3000], scores[:3000], 0.45, 1000),
+                                  C.compute_nms(boxes[:3000], scores[:3000], 0.45, 1000))
+
+
+def test_decode_nms_more_than_4096_ranks(fda):
+    rng = np.random.default_rng(37)
+    cfg = ssd_config(256)
+    boxes, _, counts = S.make_ground_truth(rng, 3, 256, gmax=24)
+    y = S.make_head_outputs(rng, cfg, boxes, counts, n_ties=300)
+    wh = rng.uniform(100, 2000, (3, 2)).astype(F32)
+    check_decode_nms(fda, cfg, y, 0.0, wh, limit=10000)            # every anchor a candidate, three launches
+    check_decode_nms(fda, cfg, y, 0.0, None, "array", limit=30000)  # limit above the anchor count
+    check_decode_nms(fda, cfg, y, 0.05, None, limit=5000)          # fewer candidates than 4096: later launches idle
+    check_decode_nms(fda, cfg, y, 0.05, wh, limit=1000)
 
 
 def test_decode_nms_more_than_1024_ranks(fda):

@@ -82,6 +82,9 @@ struct MatchArgs {
 #ifdef SSD_EXP_TRACE
     unsigned long long *tr, *tr_force;
 #endif
+#ifdef SSD_EXP_WGTRACE             // timing experiment (profiles/match_waves.py): stamps per wave
+    unsigned long long *wg;
+#endif
 };
 
 struct MatchShared {
@@ -362,6 +365,12 @@ SSD_DEV void geom_tile(const MatchArgs &p, MatchShared &sm, const MatchLayer &L,
     const float *labels = p.gt_labels + (long long)img * p.gmax;
     u64 *gkey = p.gkey + (long long)img * p.gmax;
     const unsigned n_box = (unsigned)L.n_box;
+#ifdef SSD_EXP_WGTRACE
+    unsigned long long *wg = p.wg ? p.wg + (((long long)img * gridDim.x + tile) * 4 + wave) * 4 : nullptr;
+    const unsigned long long wg_t0 = wall_clock64();
+    unsigned long long wg_t1 = 0;
+    int wg_list = 0;
+#endif
 
     // LDS tables: log-size offsets per (listed box | box 0 in slot kListCap, shape), row centres,
     // y offsets against box 0 per (row, shape)
@@ -480,6 +489,12 @@ SSD_DEV void geom_tile(const MatchArgs &p, MatchShared &sm, const MatchLayer &L,
             __syncthreads();
         }
 
+#ifdef SSD_EXP_WGTRACE
+        if (g0 == 0) {
+            wg_t1 = wall_clock64();
+            wg_list = n_list;
+        }
+#endif
 #pragma unroll 1
         for (int gi = wave; gi < n_groups_here; gi += kBlock / 64) {
             const int lr0 = gi * 2 * R;                       // the group's first row within the tile
@@ -572,6 +587,15 @@ SSD_DEV void geom_tile(const MatchArgs &p, MatchShared &sm, const MatchLayer &L,
         if (n_list != 0) flush_keys(sm, n_list, t, gkey);
         if (g0 + kListCap < G) __syncthreads();
     }
+#ifdef SSD_EXP_WGTRACE
+    if (wg != nullptr && lane == 0) {
+        __builtin_amdgcn_s_waitcnt(0);
+        wg[0] = wg_t0;
+        wg[1] = wg_t1;
+        wg[2] = wall_clock64();
+        wg[3] = ((unsigned long long)wg_list << 16) | ((unsigned long long)R << 8) | (unsigned long long)n_box;
+    }
+#endif
 }
 
 template <bool YTRUE, bool DETAILS, bool MULTI>
@@ -739,13 +763,22 @@ __global__ __launch_bounds__(kBlock) void force_kernel(const MatchArgs p)
     SSD_TRACE_END(p.tr_force);
 }
 
+#ifdef SSD_EXP_WGTRACE
+unsigned long long *g_wgtrace = nullptr;
+#endif
+
 template <bool GEOM, bool YTRUE>
 int launch_match(ssdbox_ctx *ctx, const MatchArgs &args_in, int batch, int n_tiles, size_t lds_bytes)
 {
-#ifdef SSD_EXP_TRACE
+#if defined(SSD_EXP_TRACE) || defined(SSD_EXP_WGTRACE)
     MatchArgs args = args_in;
+#ifdef SSD_EXP_TRACE
     args.tr = ssd_trace_slot(ctx, SSDBOX_STAGE_MATCH);
     args.tr_force = ssd_trace_slot(ctx, SSDBOX_STAGE_FORCE);
+#endif
+#ifdef SSD_EXP_WGTRACE
+    args.wg = g_wgtrace;
+#endif
 #else
     const MatchArgs &args = args_in;
 #endif
@@ -943,6 +976,14 @@ int match_common(ssdbox_ctx *ctx, const ssdbox_geom *geom, const float *d_anchor
 }
 
 }  // namespace
+
+#ifdef SSD_EXP_WGTRACE
+extern "C" int ssdbox_debug_set_wgtrace(void *dev_ptr)
+{
+    g_wgtrace = static_cast<unsigned long long *>(dev_ptr);
+    return 0;
+}
+#endif
 
 extern "C" int ssdbox_match_encode(ssdbox_ctx *ctx, const ssdbox_geom *geom, const float *d_anchors,
                                    int64_t num_anchors, const float *d_gt_boxes,

@@ -1,7 +1,7 @@
 """The entry point that allocates nothing (ssdbox_match_encode_static, scratch in the library's
 fixed per-GPU array) against ssdbox_match_encode, called through the C ABI: every output
-bit-identical, on two calls in a row of which the second is smaller, and sizes beyond the
-fixed array are rejected."""
+bit-identical, on two calls in a row of which the second is smaller, no device memory taken,
+captured into a HIP graph and replayed, and sizes beyond the fixed array are rejected."""
 import ctypes
 
 import numpy as np
@@ -99,6 +99,57 @@ def test_static_scratch_entry_allocates_nothing():
     assert free1 == free0, "device memory moved by %d bytes over calls that must not allocate" % (free0 - free1)
     for w, g in zip(want, (conf, locs, midx, miou)):
         assert np.array_equal(w.view(np.uint32), g.cpu().numpy().view(np.uint32))
+
+
+def test_static_scratch_entry_under_graph_capture():
+    """The caller the entry point exists for: the call is captured into a HIP graph (where an
+    allocation is an error), the graph is replayed on new inputs written into the captured
+    buffers, and every replay gives the allocating entry's result."""
+    import torch
+    from face_detection_amd import _lib
+    from face_detection_amd.runtime import Context, geometry_for
+    lib = _lib.load()
+    torch.cuda.set_device(0)
+    size, batch, gmax = 256, 5, 48
+    cfg = ssd_config(size)
+    geom = geometry_for(cfg, 0)
+    A = geom.num_anchors
+    rng = np.random.default_rng(21)
+    sets = [S.make_ground_truth(rng, batch, size, gmax=gmax) for _ in range(3)]
+    d = [torch.from_numpy(x).cuda() for x in sets[0]]
+    conf = torch.empty((batch, A), dtype=torch.float32, device="cuda")
+    locs = torch.empty((batch, A, 4), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.Stream()
+    ctx = Context(0, stream)
+
+    def call():
+        rc = lib.ssdbox_match_encode_static(ctx.handle, geom.handle, None, A, _p(d[0]), _p(d[1]), _p(d[2]), batch,
+                                            gmax, float(size), 0.5, _p(conf), _p(locs), None, None)
+        assert rc == 0, lib.ssdbox_last_error()
+    with torch.cuda.stream(stream):
+        call()                                                # warm: module load, the context's set-up
+    stream.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=stream):
+        call()
+    ref = Context(0)
+    for boxes, labels, counts in sets:
+        for dst, src in zip(d, (boxes, labels, counts)):
+            dst.copy_(torch.from_numpy(src))
+        conf.fill_(-7.0)
+        locs.fill_(-7.0)
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        w_conf = torch.empty_like(conf)
+        w_locs = torch.empty_like(locs)
+        rc = lib.ssdbox_match_encode(ref.handle, geom.handle, None, A, _p(d[0]), _p(d[1]), _p(d[2]), batch, gmax,
+                                     float(size), 0.5, _p(w_conf), _p(w_locs), None, None)
+        assert rc == 0, lib.ssdbox_last_error()
+        ref.synchronize()
+        assert np.array_equal(conf.cpu().numpy().view(np.uint32), w_conf.cpu().numpy().view(np.uint32))
+        assert np.array_equal(locs.cpu().numpy().view(np.uint32), w_locs.cpu().numpy().view(np.uint32))
+        assert (w_conf > 0).any()
 
 
 def test_static_scratch_entry_rejects_what_does_not_fit():

@@ -882,11 +882,11 @@ int match_common(ssdbox_ctx *ctx, const ssdbox_geom *geom, const float *d_anchor
     if (geom != nullptr) {
         // Tiling of this launch: fine maps get tall tiles whose waves take several groups of
         // rows; coarse maps, and every map when an image may hold more boxes than one list,
-        // one group per wave.  Tiles are numbered from the first (finest) layer to the last:
-        // workgroups start in index order, and the tall tiles of the fine maps run longest
-        // (measured against the opposite order: 27 against 29 us for the bench batch, 117
-        // against 128 us with 256 boxes in every image; images taking turns tile by tile,
-        // which interleaves the output rows of all images, 39 us).
+        // one group per wave.  Tiles are numbered from the first (finest) layer to the last; the
+        // order in which the layers' workgroups start measured within the run-to-run spread
+        // (26-30 us for the bench batch, 118-123 us with 256 boxes in every image, for six
+        // orders), only images taking turns tile by tile is slower (39 us: it interleaves the
+        // output rows of all images).
         const bool multi = gmax > kListCap;
         const GeomDev &g = geom->host;
         args.n_layers = g.n_layers;
